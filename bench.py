@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the list-render path on MI355X.
+
+Metric (BASELINE.json): Mrays/s at 1920x1080x64 spp on a 100 k-triangle synthetic OBJ mesh
+(configs[2]); rays = primary rays = nx*ny*spp (LambertShade never traces secondary rays).
+One "step" = one frame: the render kernel over the whole image (row bands over N GPUs, one
+process per GPU) + the gather of the float3 framebuffer to rank 0.  Scene, camera and RNG
+states are resident in HBM before the timed region; the RNG streams simply continue from
+frame to frame like the reference's frame loop (core/render.h:174-186).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is the HBM roofline BASELINE.json asks for
+(algorithmic bytes of the triangle stream per launch / measured kernel time / 8 TB/s);
+`cpu_baseline` is the CPU oracle (oracle/, a port — the reference cannot be built here)
+timed on a bounded crop of the same frame on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NX, NY, SPP = 1920, 1080, 64
+N_LAT, N_LON = 200, 250                     # 100 000 triangles
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+REC_BYTES = 64                              # derived triangle record (csrc/crt_device.hpp)
+
+
+def build_scene_obj(tmpdir):
+    from cudaraytracer_amd import scenes
+    sc = scenes.displaced_sphere(N_LAT, N_LON, radius=200.0, centre=(0.0, 0.0, 0.0), index_base=1)
+    path = os.path.join(tmpdir, "bunny100k_synthetic.obj")
+    scenes.write_obj(path, sc)
+    return path
+
+
+def algorithmic_bytes(nx, rows, spp, n_tris):
+    """Bytes one render launch must move if every 64-lane wavefront (8x8 pixel tile) reads
+    each 64-B triangle record once per sample, plus the float3 store and the XORWOW state
+    load/store (24 B each way) per pixel.  DESIGN.md §Roofline."""
+    tiles = ((nx + 7) // 8) * ((rows + 7) // 8)
+    px = nx * rows
+    return tiles * spp * n_tris * REC_BYTES + px * 12 + px * 48
+
+
+def cpu_baseline(obj_path, budget_rays=1536):
+    """Oracle (serial CPU port of the reference loop) on a centred crop of the same frame."""
+    from oracle import pyoracle as po
+    pts, idx = po.parse_obj(obj_path)
+    w = po.World(pts, idx, None, 1)
+    cam = po.make_camera((0, 100, 1000), (0, 150, 0), (0, 1, 0), 40.0,
+                         np.float32(NX) / np.float32(NY), 0.0, 10.0)
+    cw, ch, cs = 32, 12, 4                  # 32x12 px x 4 spp = 1536 rays x 100 k triangles
+    r0, c0 = NY // 2 - ch // 2, NX // 2 - cw // 2
+    win = (r0, r0 + ch, c0, c0 + cw)
+    po.render(w, cam, NX, NY, 1, window=(r0, r0 + 1, c0, c0 + 2))      # warm caches / tables
+    import ctypes as C
+    states = np.zeros(NX * NY, dtype=po.STATE_DTYPE)
+    L = po.lib()
+    L.o_set_curand_state_range(states.ctypes.data, 0, 1, 0)
+    for y in range(r0, r0 + ch):
+        first = y * NX + c0
+        L.o_set_curand_state_range(states[first:].ctypes.data, first, cw, 0)
+    t0 = time.perf_counter()
+    po.render(w, cam, NX, NY, cs, window=win, states=states)
+    dt = time.perf_counter() - t0
+    rays = cw * ch * cs
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": "oracle/crt_oracle.c (gcc -O2, 1 thread), centred %dx%d px crop x %d spp of the "
+                      "1920x1080 frame against all %d triangles: %d rays in %.1f s"
+                      % (cw, ch, cs, w.n_tris, rays, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--variant", type=int, default=0, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cudaraytracer_amd import _lib, api
+    from cudaraytracer_amd.dist import BandRenderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no HIP device — the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    if not os.path.exists(_lib.library_path()):
+        if local_rank == 0:
+            _lib.build_library()
+        if world > 1:
+            dist.barrier()
+    _lib.lib().crt_set_kernel_variant(args.variant)
+
+    tmpdir = tempfile.mkdtemp(prefix="crt_bench_%d_" % rank)
+    obj_path = build_scene_obj(tmpdir)
+    scene = api.Scene.from_obj(obj_path, scale=1.0)
+    camera = api.init_camera(NX, NY)                       # the reference's live camera
+    n_tris = scene.n_triangles
+    br = BandRenderer(scene, camera, NX, NY, rank, world, seed=0)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        br.render(args.spp, stream=stream)
+        full = br.gather()
+        return full
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(api.last_kernel_ms())             # HIP events on the launch stream
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        rays = NX * NY * args.spp * args.steps
+        value = rays / elapsed / 1e6
+        k_ms = float(np.mean(kernel_ms))
+        alg = algorithmic_bytes(NX, br.row_count, args.spp, n_tris)
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs peak",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %dx%d, %d spp, %d-triangle synthetic OBJ mesh "
+                                   "(displaced sphere; bunny.obj is absent from the reference), "
+                                   "brute-force triangle list, reference camera" % (NX, NY, args.spp, n_tris),
+                       "nx": NX, "ny": NY, "spp": args.spp, "triangles": n_tris,
+                       "parallelism": "row-bands x%d + 1 gather" % world,
+                       "kernel_variant": args.variant},
+            "gtests_per_s": value * n_tris / 1e3,
+            "kernel_ms": k_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "render_list_kernel", "algorithmic_bytes_per_launch": alg},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(obj_path)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

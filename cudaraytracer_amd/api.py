@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's host interface for the list-render path, on top of
+the C ABI (include/crt.h).  Function names, argument meaning and error behaviour follow the
+reference (paths relative to CudaTest/src):
+
+    create_camera / init_camera     createScene.h:142-165
+    create_FBXMesh                  createScene.h:192-210  (mesh arrays instead of an FBXObject)
+    SetCurandState                  core/deviceManage.h:130-136
+    renderListAnimation             core/render.h:159-189
+    WritePng                        core/render.h:135-157
+
+torch is used only as plumbing: it owns the device colour buffer and the stream.
+Errors raise CrtError (the reference prints and exit()s, core/deviceManage.h:3-17).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import CrtCamera, CrtError, check, check_handle
+
+DEFAULT_ALBEDO = (0.65, 0.05, 0.05)     # createScene.h:180
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class Camera:
+    """Camera** camera of the reference; holds a crt_camera (core/camera.h:46-52)."""
+
+    def __init__(self, lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist):
+        self.c = CrtCamera()
+        _lib.lib().crt_camera_make(C.byref(self.c), _f3(lookfrom), _f3(lookat), _f3(vup),
+                                   float(vfov), float(aspect), float(aperture), float(focus_dist))
+
+    def as_array(self):
+        c = self.c
+        return np.array(list(c.lower_left_corner) + list(c.horizontal) + list(c.vertical) +
+                        list(c.origin) + list(c.x) + list(c.y) + list(c.z) + [c.lens_radius],
+                        dtype=np.float32)
+
+
+def create_camera(nx, ny, lookfrom, lookat, dist_to_focus, aperture, vfov):
+    """create_camera kernel, createScene.h:142-154: vup (0,1,0), aspect float(nx)/float(ny)."""
+    aspect = np.float32(nx) / np.float32(ny)
+    return Camera(lookfrom, lookat, (0.0, 1.0, 0.0), vfov, aspect, aperture, dist_to_focus)
+
+
+def init_camera(nx, ny):
+    """init_camera, createScene.h:156-165: the live call site's camera."""
+    return create_camera(nx, ny, (0, 100, 1000), (0, 150, 0), 10.0, 0.0, 40)
+
+
+class Scene:
+    """HitableList** world of the reference: a device-resident triangle list."""
+
+    def __init__(self, handle):
+        self.handle = check_handle(handle)
+
+    @classmethod
+    def from_mesh(cls, points, idx3f, normals=None, index_base=0, albedo=DEFAULT_ALBEDO):
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(idx3f, dtype=np.float32).reshape(-1, 3)
+        nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        if nrm is not None and len(nrm) != len(idx):
+            raise CrtError(_lib.CRT_ERR_INVALID, "one face normal per triangle is required")
+        alb = np.array(albedo, dtype=np.float32)
+        h = _lib.lib().crt_scene_from_mesh(_fp(pts), len(pts), _fp(idx), len(idx),
+                                           None if nrm is None else _fp(nrm), int(index_base), _fp(alb))
+        return cls(h)
+
+    @classmethod
+    def from_obj(cls, path, scale=100.0, albedo=DEFAULT_ALBEDO):
+        alb = np.array(albedo, dtype=np.float32)
+        return cls(_lib.lib().crt_scene_from_obj(os.fsencode(path), float(scale), _fp(alb)))
+
+    @property
+    def n_triangles(self):
+        return _lib.lib().crt_scene_triangle_count(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().crt_scene_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_FBXMesh(points, idxVertex, normals, albedo=DEFAULT_ALBEDO):
+    """create_FBXMesh, createScene.h:192-210: 0-based float-triplet indices + face normals."""
+    return Scene.from_mesh(points, idxVertex, normals, 0, albedo)
+
+
+def parse_obj(path):
+    """parseObjByName, Loader/obj_loader.h:20-111 (+ mean centring): (points, idxVertex)."""
+    L = _lib.lib()
+    n_p, n_t = C.c_int(), C.c_int()
+    check(L.crt_parse_obj(os.fsencode(path), None, None, C.byref(n_p), C.byref(n_t)))
+    pts = np.zeros((n_p.value, 3), dtype=np.float32)
+    idx = np.zeros((n_t.value, 3), dtype=np.float32)
+    check(L.crt_parse_obj(os.fsencode(path), _fp(pts), _fp(idx), C.byref(n_p), C.byref(n_t)))
+    return pts, idx
+
+
+class CurandState:
+    """curandState* curand_state of the reference for the pixels [first, first+count)."""
+
+    def __init__(self, first_pixel, count, seed=0):
+        self.first, self.count = int(first_pixel), int(count)
+        self.handle = check_handle(_lib.lib().crt_rng_create(self.first, self.count, int(seed)))
+
+    def reset(self, seed=0):
+        check(_lib.lib().crt_rng_reset(self.handle, int(seed)))
+
+    def export(self):
+        out = np.zeros((self.count, 6), dtype=np.uint32)
+        check(_lib.lib().crt_rng_export(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().crt_rng_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def SetCurandState(nx, ny, seed=0, row_begin=0, row_count=None):
+    """SetCurandState, core/deviceManage.h:130-136 (curand_init(0, pixel_index, 0)); a rank
+    that owns a row band asks only for its rows."""
+    rows = ny - row_begin if row_count is None else row_count
+    return CurandState(row_begin * nx, rows * nx, seed)
+
+
+def render_rows(scene, camera, curand_state, nx, ny, samples, row_begin, row_count, d_rgb,
+                max_depth=8, frame_index=0, stream=None):
+    """One launch of the render kernel (core/render.h:105-129) on rows
+    [row_begin, row_begin+row_count).  d_rgb: torch CUDA float32 tensor with
+    row_count*nx*3 elements (or a raw device pointer int)."""
+    ptr = d_rgb if isinstance(d_rgb, int) else d_rgb.data_ptr()
+    sptr = None
+    if stream is not None:
+        sptr = stream if isinstance(stream, int) else stream.cuda_stream
+    check(_lib.lib().crt_render_rows(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny,
+                                     samples, max_depth, frame_index, row_begin, row_count,
+                                     C.c_void_p(ptr), C.c_void_p(sptr)))
+
+
+def last_kernel_ms():
+    ms = _lib.lib().crt_last_kernel_ms()
+    if ms < 0:
+        raise CrtError(_lib.CRT_ERR_HIP, _lib.lib().crt_last_error().decode())
+    return ms
+
+
+def render(nx, ny, samples, scene, camera, seed=0, max_depth=8, frame_index=0):
+    """One frame through crt_render: float32 array [ny, nx, 3], row 0 = image bottom."""
+    out = np.zeros((ny, nx, 3), dtype=np.float32)
+    check(_lib.lib().crt_render(nx, ny, samples, max_depth, frame_index, scene.handle,
+                                C.byref(camera.c), int(seed), _fp(out)))
+    return out
+
+
+def to_rgba8(rgb):
+    ny, nx, _ = rgb.shape
+    b = np.ascontiguousarray(rgb, dtype=np.float32)
+    out = np.zeros((ny, nx, 4), dtype=np.uint8)
+    _lib.lib().crt_to_rgba8(_fp(b), nx, ny, out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return out
+
+
+def WritePng(nx, ny, frameIndex, colorBuffer, folder="images/moveTest"):
+    """WritePng, core/render.h:135-157: images/moveTest/picture_<frame>.png (the folder is
+    created here; the reference requires it to exist)."""
+    os.makedirs(folder, exist_ok=True)
+    path = os.path.join(folder, "picture_%d.png" % frameIndex)
+    b = np.ascontiguousarray(colorBuffer, dtype=np.float32).reshape(ny, nx, 3)
+    check(_lib.lib().crt_write_png(os.fsencode(path), nx, ny, _fp(b)))
+    return path
+
+
+def renderListAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world, camera,
+                        curand_state, write_png=True, folder="images/moveTest"):
+    """renderListAnimation, core/render.h:159-189 for a static mesh: per frame launch the
+    render kernel on the whole image, synchronise, copy back, WritePng.  The RNG states
+    persist across frames as in the reference.  Returns the list of frames."""
+    import torch
+    if not torch.cuda.is_available():
+        raise CrtError(_lib.CRT_ERR_NO_DEVICE, "renderListAnimation: no HIP device (no CPU fallback)")
+    d_colorBuffer = torch.zeros(ny * nx * 3, dtype=torch.float32, device="cuda")
+    frames = []
+    for frameIndex in range(beginFrame, endFrame + 1):
+        render_rows(world, camera, curand_state, nx, ny, samples, 0, ny, d_colorBuffer,
+                    max_depth=max_depth, frame_index=frameIndex,
+                    stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        colorBuffer = d_colorBuffer.cpu().numpy().reshape(ny, nx, 3)
+        if write_png:
+            WritePng(nx, ny, frameIndex, colorBuffer, folder)
+        frames.append(colorBuffer)
+    return frames

@@ -1,0 +1,469 @@
+// crt_api.cpp — the C ABI of libcrt_hip.so (include/crt.h): host side of the list-render
+// path.  Mirrors the reference's host functions (paths relative to CudaTest/src):
+//   SetCurandState            core/deviceManage.h:130-136   -> crt_rng_create / crt_rng_reset
+//   init_camera/create_camera createScene.h:142-165          -> crt_camera_make
+//   create_FBXMesh            createScene.h:192-210          -> crt_scene_from_mesh
+//   parseObjByName            Loader/obj_loader.h:20-133     -> crt_parse_obj / crt_scene_from_obj
+//   renderListAnimation       core/render.h:159-189          -> crt_render / crt_render_rows
+//   WritePng                  core/render.h:135-157          -> crt_to_rgba8 / crt_write_png
+// There is no CPU compute path in this library: without a HIP device every compute entry
+// point returns CRT_ERR_NO_DEVICE.
+#include "../../include/crt.h"
+#include "crt_device.hpp"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+thread_local std::string g_err;
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+thread_local bool g_ev_valid = false;
+thread_local int g_variant = 0;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(CRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+bool have_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return n > 0;
+}
+
+// ---------------------------------------------------------------- XORWOW jump matrices
+// J_k = T^(2^(67+k)) for k = 0..63, T = GF(2) transition matrix of the xorshift part of
+// cuRAND's XORWOW (row-vector convention: row b = image of state bit b).
+struct Mat {
+    uint32_t row[crt::kXwBits][crt::kXwWords];
+};
+
+void mat_vec(const uint32_t* vec, const Mat& m, uint32_t* out) {
+    uint32_t r[crt::kXwWords] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < crt::kXwWords; ++w) {
+        uint32_t word = vec[w];
+        while (word) {
+            int b = __builtin_ctz(word);
+            word &= word - 1;
+            const uint32_t* row = m.row[w * 32 + b];
+            for (int k = 0; k < crt::kXwWords; ++k) r[k] ^= row[k];
+        }
+    }
+    for (int k = 0; k < crt::kXwWords; ++k) out[k] = r[k];
+}
+
+void mat_square(Mat& m) {
+    Mat* t = new Mat;
+    for (int r = 0; r < crt::kXwBits; ++r) mat_vec(m.row[r], m, t->row[r]);
+    m = *t;
+    delete t;
+}
+
+const std::vector<uint32_t>& jump_table() {
+    static std::vector<uint32_t> table;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        Mat* m = new Mat;
+        for (int b = 0; b < crt::kXwBits; ++b) {
+            uint32_t v[crt::kXwWords] = {0, 0, 0, 0, 0};
+            v[b / 32] = 1u << (b % 32);
+            uint32_t t = v[0] ^ (v[0] >> 2);
+            v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = v[4];
+            v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+            for (int k = 0; k < crt::kXwWords; ++k) m->row[b][k] = v[k];
+        }
+        for (int i = 0; i < 67; ++i) mat_square(*m);
+        table.resize((size_t)crt::kXwJumps * crt::kXwBits * crt::kXwWords);
+        for (int k = 0; k < crt::kXwJumps; ++k) {
+            memcpy(&table[(size_t)k * crt::kXwBits * crt::kXwWords], m->row, sizeof(Mat));
+            if (k + 1 < crt::kXwJumps) mat_square(*m);
+        }
+        delete m;
+    });
+    return table;
+}
+
+// ---------------------------------------------------------------- host vec3 helpers
+struct H3 {
+    float x, y, z;
+};
+H3 h3(const float* p) { return H3{p[0], p[1], p[2]}; }
+H3 hsub(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+H3 hmul(float t, H3 v) { return H3{t * v.x, t * v.y, t * v.z}; }
+H3 hcross(H3 a, H3 b) {   // core/vec3.h:113-117
+    return H3{(a.y * b.z - a.z * b.y), (-(a.x * b.z - a.z * b.x)), (a.x * b.y - a.y * b.x)};
+}
+H3 hunit(H3 v) {          // core/vec3.h:191-193
+    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return H3{v.x / len, v.y / len, v.z / len};
+}
+// rotate(origin, rotation) of core/vec3.h:200-217, literally (used with rotation 0 only).
+H3 hrotate(H3 o, H3 rot) {
+    float radiansX = (float)((M_PI / 180.) * rot.x);
+    float sin_X = sinf(radiansX), cos_X = cosf(radiansX);
+    float radiansY = (float)((M_PI / 180.) * rot.y);
+    float sin_Y = sinf(radiansY), cos_Y = cosf(radiansY);
+    float radiansZ = (float)(-(M_PI / 180.) * rot.z);
+    float sin_Z = sinf(radiansZ), cos_Z = cosf(radiansZ);
+    H3 r0{cos_Y * cos_Z, -cos_Y * sin_Z, sin_Y};
+    H3 r1{sin_X * sin_Y * cos_Z + cos_X * sin_Z, -sin_X * sin_Y * sin_Z + cos_X * cos_Z, -sin_X * cos_Y};
+    H3 r2{-cos_X * sin_Y * cos_Z + sin_X * sin_Z, cos_X * sin_Y * sin_Z + sin_X * cos_Z, cos_X * cos_Y};
+    return H3{o.x * r0.x + o.y * r0.y + o.z * r0.z, o.x * r1.x + o.y * r1.y + o.z * r1.z,
+              o.x * r2.x + o.y * r2.y + o.z * r2.z};
+}
+
+}  // namespace
+
+struct crt_scene {
+    int n_tris = 0;
+    int device = 0;
+    float albedo[3] = {0, 0, 0};
+    float* d_base = nullptr;      // n x 12: v0 v1 v2 n
+    float* d_shade_n = nullptr;   // n x 3: normal after the two rotate() calls of Hitable::hit
+    float* d_rec = nullptr;       // n x 16 derived records (prepass output)
+};
+
+struct crt_rng {
+    long long first = 0, count = 0;
+    int device = 0;
+    uint32_t* d_state = nullptr;  // SoA 6 x count: d, v0..v4
+    uint32_t* d_jump = nullptr;
+};
+
+extern "C" {
+
+int crt_abi_version(void) { return CRT_ABI_VERSION; }
+
+const char* crt_last_error(void) { return g_err.c_str(); }
+
+int crt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void crt_camera_make(crt_camera* out, const float lookfrom_[3], const float lookat_[3],
+                     const float vup_[3], float vfov, float aspect, float aperture,
+                     float focus_dist) {
+    // Camera::Camera, core/camera.h:18-38
+    H3 lookfrom = h3(lookfrom_), lookat = h3(lookat_), vup = h3(vup_);
+    out->lens_radius = aperture / 2.0f;
+    float theta = (float)(vfov * M_PI / 180.0f);   // double product/quotient, one rounding
+    float half_height = tanf(theta / 2.0f);
+    float half_width = half_height * aspect;
+    H3 origin = lookfrom;
+    H3 z = hunit(hsub(lookfrom, lookat));
+    H3 x = hunit(hcross(vup, z));
+    H3 y = hcross(z, x);
+    H3 llc = hsub(hsub(hsub(origin, hmul(half_width * focus_dist, x)), hmul(half_height * focus_dist, y)),
+                  hmul(focus_dist, z));
+    H3 hor = hmul(2.0f * half_width * focus_dist, x);
+    H3 ver = hmul(2.0f * half_height * focus_dist, y);
+    auto put = [](float* d, H3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; };
+    put(out->lower_left_corner, llc);
+    put(out->horizontal, hor);
+    put(out->vertical, ver);
+    put(out->origin, origin);
+    put(out->x, x);
+    put(out->y, y);
+    put(out->z, z);
+}
+
+crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* idx3f, int n_tris,
+                               const float* face_normals, int index_base, const float albedo[3]) {
+    if (!points || !idx3f || !albedo || n_points <= 0 || n_tris < 0) {
+        fail(CRT_ERR_INVALID, "crt_scene_from_mesh: null pointer or non-positive size");
+        return nullptr;
+    }
+    if (!have_device()) {
+        fail(CRT_ERR_NO_DEVICE, "crt_scene_from_mesh: no HIP device");
+        return nullptr;
+    }
+    std::vector<float> base((size_t)std::max(n_tris, 1) * crt::kBaseFloats);
+    std::vector<float> shade((size_t)std::max(n_tris, 1) * 3);
+    for (int i = 0; i < n_tris; ++i) {
+        int id[3];
+        for (int k = 0; k < 3; ++k) {
+            id[k] = (int)idx3f[3 * (size_t)i + k] - index_base;   // int(idx[k]), createScene.h:183
+            if (id[k] < 0 || id[k] >= n_points) {
+                fail(CRT_ERR_INVALID, "crt_scene_from_mesh: triangle %d references vertex %d of %d", i,
+                     id[k], n_points);
+                return nullptr;
+            }
+        }
+        float* b = &base[(size_t)i * crt::kBaseFloats];
+        for (int k = 0; k < 3; ++k)   // v = {points[idx[2]], points[idx[1]], points[idx[0]]}
+            memcpy(b + 3 * k, points + 3 * (size_t)id[2 - k], 3 * sizeof(float));
+        H3 n;
+        if (face_normals) {           // 6-argument Triangle ctor, shapes/triangle.h:21-29
+            n = h3(face_normals + 3 * (size_t)i);
+        } else {                      // 5-argument ctor, shapes/triangle.h:14-17
+            H3 e1 = hsub(h3(b + 3), h3(b));
+            H3 e2 = hsub(h3(b + 6), h3(b));
+            n = hunit(hcross(e1, e2));
+        }
+        b[9] = n.x; b[10] = n.y; b[11] = n.z;
+        // rec.normal = rotate(rec.normal, transform->rotation) at the triangle and again
+        // at the world list (hitable/hitable.h:36), both with rotation 0.
+        H3 sn = hrotate(hrotate(n, H3{0, 0, 0}), H3{0, 0, 0});
+        shade[3 * (size_t)i] = sn.x; shade[3 * (size_t)i + 1] = sn.y; shade[3 * (size_t)i + 2] = sn.z;
+    }
+    crt_scene* s = new (std::nothrow) crt_scene;
+    if (!s) { fail(CRT_ERR_NOMEM, "crt_scene_from_mesh: out of memory"); return nullptr; }
+    s->n_tris = n_tris;
+    memcpy(s->albedo, albedo, sizeof s->albedo);
+    hipError_t e = hipGetDevice(&s->device);
+    size_t nalloc = (size_t)std::max(n_tris, 1);
+    if (e == hipSuccess) e = hipMalloc(&s->d_base, nalloc * crt::kBaseFloats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&s->d_shade_n, nalloc * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&s->d_rec, nalloc * crt::kRecFloats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(s->d_base, base.data(), nalloc * crt::kBaseFloats * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_shade_n, shade.data(), nalloc * 3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        fail(CRT_ERR_HIP, "crt_scene_from_mesh: %s", hipGetErrorString(e));
+        crt_scene_free(s);
+        return nullptr;
+    }
+    return s;
+}
+
+int crt_parse_obj(const char* path, float* points, float* idx3f, int* n_points, int* n_tris) {
+    if (!path || !n_points || !n_tris) return fail(CRT_ERR_INVALID, "crt_parse_obj: null argument");
+    FILE* f = fopen(path, "r");
+    if (!f) return fail(CRT_ERR_IO, "crt_parse_obj: cannot open %s", path);
+    int np = 0, nt = 0;
+    char line[2048];
+    auto three = [](const char* p, float out[3]) {
+        // `ss >> a >> b >> c` on floats (Loader/obj_loader.h:49,62): leading number of each token
+        for (int k = 0; k < 3; ++k) {
+            while (*p == ' ' || *p == '\t') ++p;
+            char* end = nullptr;
+            out[k] = strtof(p, &end);
+            if (end == p) { out[k] = 0.0f; return; }
+            p = end;
+            while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') ++p;   // skip "/vt/vn"
+        }
+    };
+    while (fgets(line, sizeof line, f)) {
+        const char* p = line;
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            float v[3] = {0, 0, 0};
+            three(p + 1, v);
+            if (points) memcpy(points + 3 * (size_t)np, v, sizeof v);
+            ++np;
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            float v[3] = {0, 0, 0};
+            three(p + 1, v);
+            if (idx3f) memcpy(idx3f + 3 * (size_t)nt, v, sizeof v);   // kept as floats, 1-based
+            ++nt;
+        }
+    }
+    fclose(f);
+    *n_points = np;
+    *n_tris = nt;
+    if (points && np > 0) {
+        // computeMean + centering, Loader/obj_loader.h:120-133 (fp32 running sum, true divide)
+        float mx = 0, my = 0, mz = 0;
+        for (int i = 0; i < np; ++i) { mx += points[3 * (size_t)i]; my += points[3 * (size_t)i + 1]; mz += points[3 * (size_t)i + 2]; }
+        float fn = (float)np;
+        mx = mx / fn; my = my / fn; mz = mz / fn;
+        for (int i = 0; i < np; ++i) { points[3 * (size_t)i] -= mx; points[3 * (size_t)i + 1] -= my; points[3 * (size_t)i + 2] -= mz; }
+    }
+    return CRT_OK;
+}
+
+crt_scene* crt_scene_from_obj(const char* path, float scale, const float albedo[3]) {
+    int np = 0, nt = 0;
+    if (crt_parse_obj(path, nullptr, nullptr, &np, &nt) != CRT_OK) return nullptr;
+    if (np <= 0) { fail(CRT_ERR_IO, "crt_scene_from_obj: %s has no vertices", path); return nullptr; }
+    std::vector<float> pts((size_t)np * 3), idx((size_t)std::max(nt, 1) * 3);
+    if (crt_parse_obj(path, pts.data(), idx.data(), &np, &nt) != CRT_OK) return nullptr;
+    for (size_t i = 0; i < pts.size(); ++i) pts[i] *= scale;   // points[i] *= 100.0, obj_loader.h:164
+    return crt_scene_from_mesh(pts.data(), np, idx.data(), nt, nullptr, 1, albedo);
+}
+
+int crt_scene_triangle_count(const crt_scene* s) { return s ? s->n_tris : CRT_ERR_INVALID; }
+
+void crt_scene_free(crt_scene* s) {
+    if (!s) return;
+    if (s->d_base) (void)hipFree(s->d_base);
+    if (s->d_shade_n) (void)hipFree(s->d_shade_n);
+    if (s->d_rec) (void)hipFree(s->d_rec);
+    delete s;
+}
+
+crt_rng* crt_rng_create(int64_t first_pixel, int64_t count, uint64_t seed) {
+    if (first_pixel < 0 || count <= 0) { fail(CRT_ERR_INVALID, "crt_rng_create: bad pixel range"); return nullptr; }
+    if (!have_device()) { fail(CRT_ERR_NO_DEVICE, "crt_rng_create: no HIP device"); return nullptr; }
+    crt_rng* r = new (std::nothrow) crt_rng;
+    if (!r) { fail(CRT_ERR_NOMEM, "crt_rng_create: out of memory"); return nullptr; }
+    r->first = first_pixel;
+    r->count = count;
+    const std::vector<uint32_t>& jt = jump_table();
+    hipError_t e = hipGetDevice(&r->device);
+    if (e == hipSuccess) e = hipMalloc(&r->d_state, (size_t)count * 6 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&r->d_jump, jt.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(r->d_jump, jt.data(), jt.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        fail(CRT_ERR_HIP, "crt_rng_create: %s", hipGetErrorString(e));
+        crt_rng_free(r);
+        return nullptr;
+    }
+    if (crt_rng_reset(r, seed) != CRT_OK) { crt_rng_free(r); return nullptr; }
+    return r;
+}
+
+int crt_rng_reset(crt_rng* r, uint64_t seed) {
+    if (!r) return fail(CRT_ERR_INVALID, "crt_rng_reset: null handle");
+    HIP_TRY(crt::launch_rng_init(r->d_state, r->first, r->count, seed, r->d_jump, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return CRT_OK;
+}
+
+int crt_rng_export(const crt_rng* r, uint32_t* out6) {
+    if (!r || !out6) return fail(CRT_ERR_INVALID, "crt_rng_export: null argument");
+    std::vector<uint32_t> soa((size_t)r->count * 6);
+    HIP_TRY(hipMemcpy(soa.data(), r->d_state, soa.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (long long i = 0; i < r->count; ++i)
+        for (int k = 0; k < 6; ++k) out6[(size_t)i * 6 + k] = soa[(size_t)k * r->count + i];
+    return CRT_OK;
+}
+
+void crt_rng_free(crt_rng* r) {
+    if (!r) return;
+    if (r->d_state) (void)hipFree(r->d_state);
+    if (r->d_jump) (void)hipFree(r->d_jump);
+    delete r;
+}
+
+int crt_set_kernel_variant(int variant) {
+    int prev = g_variant;
+    g_variant = variant;
+    return prev;
+}
+
+int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
+                    int samples, int max_depth, int frame_index, int row_begin, int row_count,
+                    float* d_rgb, void* stream_) {
+    (void)max_depth;
+    (void)frame_index;
+    if (!scene || !camera || !rng || !d_rgb) return fail(CRT_ERR_INVALID, "crt_render_rows: null argument");
+    if (nx <= 0 || ny <= 0 || samples < 0 || row_begin < 0 || row_count <= 0 || row_begin + row_count > ny)
+        return fail(CRT_ERR_INVALID, "crt_render_rows: bad image/row range (nx=%d ny=%d rows %d+%d)", nx, ny, row_begin, row_count);
+    if ((long long)nx * ny > 0x7fffffffLL)
+        return fail(CRT_ERR_INVALID, "crt_render_rows: nx*ny exceeds the reference's int pixel_index (core/render.h:111)");
+    if (camera->lens_radius != 0.0f)
+        return fail(CRT_ERR_UNSUPPORTED,
+                    "crt_render_rows: aperture != 0 is a data race on state[0] in the reference (core/render.h:118)");
+    long long first = (long long)row_begin * nx, count = (long long)row_count * nx;
+    if (rng->first != first || rng->count != count)
+        return fail(CRT_ERR_INVALID, "crt_render_rows: rng covers pixels [%lld,+%lld), rows need [%lld,+%lld)",
+                    rng->first, rng->count, first, count);
+    hipStream_t stream = (hipStream_t)stream_;
+
+    HIP_TRY(crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, scene->d_rec, stream));
+
+    crt::RenderParams p;
+    memcpy(p.cam.llc, camera->lower_left_corner, 12);
+    memcpy(p.cam.horizontal, camera->horizontal, 12);
+    memcpy(p.cam.vertical, camera->vertical, 12);
+    memcpy(p.cam.origin, camera->origin, 12);
+    memcpy(p.albedo, scene->albedo, 12);
+    p.nx = nx; p.ny = ny; p.samples = samples;
+    p.row_begin = row_begin; p.row_count = row_count;
+    p.n_tris = scene->n_tris;
+    p.rng_first_pixel = first;
+    p.rng_count = count;
+
+    if (!g_ev_start) {
+        HIP_TRY(hipEventCreate(&g_ev_start));
+        HIP_TRY(hipEventCreate(&g_ev_stop));
+    }
+    HIP_TRY(hipEventRecord(g_ev_start, stream));
+    HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_shade_n, rng->d_state, d_rgb, g_variant, stream));
+    HIP_TRY(hipEventRecord(g_ev_stop, stream));
+    g_ev_valid = true;
+    return CRT_OK;
+}
+
+float crt_last_kernel_ms(void) {
+    if (!g_ev_valid) { fail(CRT_ERR_INVALID, "crt_last_kernel_ms: no kernel launched on this thread"); return -1.0f; }
+    if (hipEventSynchronize(g_ev_stop) != hipSuccess) { fail(CRT_ERR_HIP, "crt_last_kernel_ms: event sync failed"); return -1.0f; }
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, g_ev_start, g_ev_stop) != hipSuccess) { fail(CRT_ERR_HIP, "crt_last_kernel_ms: elapsed failed"); return -1.0f; }
+    return ms;
+}
+
+int crt_render(int nx, int ny, int samples, int max_depth, int frame_index, const crt_scene* scene,
+               const crt_camera* camera, uint64_t seed, float* rgb_out) {
+    if (!rgb_out) return fail(CRT_ERR_INVALID, "crt_render: null output");
+    if (nx <= 0 || ny <= 0) return fail(CRT_ERR_INVALID, "crt_render: bad image size");
+    if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_render: no HIP device");
+    crt_rng* rng = crt_rng_create(0, (int64_t)nx * ny, seed);
+    if (!rng) return CRT_ERR_HIP;
+    float* d_rgb = nullptr;
+    size_t bytes = (size_t)nx * ny * 3 * sizeof(float);
+    hipError_t e = hipMalloc(&d_rgb, bytes);
+    if (e != hipSuccess) { crt_rng_free(rng); return fail(CRT_ERR_HIP, "crt_render: %s", hipGetErrorString(e)); }
+    int rc = crt_render_rows(scene, camera, rng, nx, ny, samples, max_depth, frame_index, 0, ny, d_rgb, nullptr);
+    if (rc == CRT_OK) {
+        e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess) e = hipMemcpy(rgb_out, d_rgb, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(CRT_ERR_HIP, "crt_render: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_rgb);
+    crt_rng_free(rng);
+    return rc;
+}
+
+void crt_to_rgba8(const float* rgb, int nx, int ny, unsigned char* rgba) {
+    // WritePng, core/render.h:138-146: row i of the PNG is buffer row ny-1-i;
+    // channel = char(255.99 * c) -> double product, truncation, low 8 bits; NaN -> 0.
+    for (int i = 0; i < ny; ++i)
+        for (int j = 0; j < nx; ++j) {
+            size_t src = ((size_t)(ny - 1 - i) * nx + j) * 3, dst = ((size_t)i * nx + j) * 4;
+            for (int c = 0; c < 3; ++c) {
+                double d = 255.99 * (double)rgb[src + c];
+                int iv = (d != d) ? 0 : (int)d;
+                rgba[dst + c] = (unsigned char)iv;
+            }
+            rgba[dst + 3] = 255;
+        }
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// crt_device.hpp — shared declarations between the C-ABI host layer (crt_api.cpp) and the
+// gfx950 kernels (crt_kernels.hip).  MI355X only; compiled with
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+// The no-contraction flag is part of the numerical contract: every fp32 operation of the
+// reference is evaluated separately (mul, then add), never fused.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crt {
+
+// Base triangle record, camera independent (scene pack, createScene.h:175-190):
+//   v0, v1, v2 (reversed winding already applied), stored normal.   12 floats = 48 B.
+constexpr int kBaseFloats = 12;
+
+// Derived record for a pinhole camera at origin o: 16 floats = 64 B = one s_load_dwordx16.
+//   [0..2]   n   stored normal                    (cull test, shapes/triangle.h:61)
+//   [3..5]   e2  v2 - v0                          (triangle.h:70)
+//   [6..8]   e1  v1 - v0                          (triangle.h:69)
+//   [9..11]  s   o - v0                           (triangle.h:81; same for every ray)
+//   [12..14] q   cross(s, e1)                     (triangle.h:87)
+//   [15]     tq  dot(e2, q)                       (triangle.h:92)
+// Everything is computed with the reference's own operation order, so the values are the
+// ones Triangle::collision_detection recomputes for every ray.
+constexpr int kRecFloats = 16;
+
+// EPSILON of both Triangle ctors the scene pack can reach (shapes/triangle.h:9,22).
+constexpr float kTriEpsilon = 0.000001f;
+
+struct CameraPOD {
+    float llc[3], horizontal[3], vertical[3], origin[3];
+};
+
+struct RenderParams {
+    CameraPOD cam;
+    float albedo[3];
+    int nx, ny, samples;
+    int row_begin, row_count;
+    int n_tris;
+    long long rng_first_pixel;   // global pixel index of rng state element 0
+    long long rng_count;         // number of states (SoA stride)
+};
+
+// XORWOW jump table: J_k = T^(2^(67+k)), k = 0..63; row-vector convention,
+// 160 rows x 5 words per matrix.
+constexpr int kXwWords = 5;
+constexpr int kXwBits = 160;
+constexpr int kXwJumps = 64;
+
+// Launchers (defined in crt_kernels.hip).
+hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long count,
+                           uint64_t seed, const uint32_t* d_jump, hipStream_t stream);
+hipError_t launch_tri_prepass(const float* d_base, int n_tris, const float origin[3],
+                              float* d_rec, hipStream_t stream);
+hipError_t launch_render(const RenderParams& p, const float* d_rec, const float* d_shade_n,
+                         uint32_t* d_state, float* d_rgb, int variant, hipStream_t stream);
+
+}  // namespace crt

@@ -1,0 +1,338 @@
+// crt_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the list-render path.
+//
+// What the reference does per pixel (core/render.h:105-129 and callees, paths relative
+// to CudaTest/src of the reference) is reproduced bit for bit; how it is done is not:
+//
+//   * The reference chases Hitable** -> Triangle (80 B) -> Transform (36 B) per ray and
+//     triangle and redoes two normalisations and 18 sin/cos there (hitable.h:29-38,
+//     transform.h:11-54).  All triangles carry the identity Transform(0,0,1)
+//     (createScene.h:184), so the direction every Triangle::collision_detection sees is
+//     d2 = unit(unit(d0)) — per ray, not per triangle — and rotate(.,0) is the identity.
+//   * The camera is a pinhole on this path (aperture 0 at every call site,
+//     createScene.h:157-160), so s = o - v0, q = cross(s,e1) and dot(e2,q) are per
+//     triangle, not per ray: a prepass computes them once per frame with the reference's
+//     operation order and the render kernel reads one 64-B record per triangle.
+//   * One lane = one pixel (samples of a pixel are chained through its RNG stream, so the
+//     sample loop stays serial per lane); one wavefront = one 8x8 pixel tile.  The
+//     triangle index is wave-uniform, so the record is fetched with scalar loads
+//     (s_load_dwordx16 through the scalar cache) and feeds the VALU as SGPR operands:
+//     no VGPRs, no LDS bandwidth and no VALU slots are spent on broadcasting it.
+//   * After each of the reference's rejection tests the wavefront votes
+//     (__builtin_amdgcn_ballot_w64) and leaves the triangle as soon as no lane is alive.
+//
+// No fused multiply-add may be formed anywhere in this file (-ffp-contract=off).
+#include "crt_device.hpp"
+
+#include <float.h>
+
+namespace crt {
+
+// ------------------------------------------------------------------ XORWOW (cuRAND)
+// curand(curandStateXORWOW_t*) of CUDA 12.2's curand_kernel.h, restated.
+struct Xorwow {
+    uint32_t d, v0, v1, v2, v3, v4;
+};
+
+__device__ __forceinline__ uint32_t xw_next(Xorwow& s) {
+    uint32_t t = (s.v0 ^ (s.v0 >> 2));
+    s.v0 = s.v1;
+    s.v1 = s.v2;
+    s.v2 = s.v3;
+    s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v4 + s.d;
+}
+
+// _curand_uniform: x * 2^-32 + 2^-33, two roundings, result in (0, 1].
+__device__ __forceinline__ float xw_uniform(Xorwow& s) {
+    uint32_t x = xw_next(s);
+    const float k = 2.3283064e-10f;
+    return (float)x * k + (k / 2.0f);
+}
+
+// random_init (core/deviceManage.h:120-128): curand_init(seed, pixel_index, 0).
+// The 2^67-step subsequence skip is a product of precomputed GF(2) matrices
+// J_k = T^(2^(67+k)), one per set bit of pixel_index.  Matrix rows are wave-uniform
+// scalar loads; each lane masks them with its own state bits.
+__global__ void __launch_bounds__(256)
+rng_init_kernel(uint32_t* __restrict__ state, long long first_pixel, long long count,
+                uint32_t seed_lo, uint32_t seed_hi, const uint32_t* __restrict__ jump, int nbits) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < count;
+    unsigned long long pi = (unsigned long long)(first_pixel + (live ? i : 0));
+
+    // _curand_init_scratch seed scrambling
+    uint32_t s0 = seed_lo ^ 0xaad26b49u;
+    uint32_t s1 = seed_hi ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    uint32_t d = 6615241u + t1 + t0;
+    uint32_t v[kXwWords];
+    v[0] = 123456789u + t0;
+    v[1] = 362436069u ^ t0;
+    v[2] = 521288629u + t1;
+    v[3] = 88675123u ^ t1;
+    v[4] = 5783321u + t0;
+
+    for (int k = 0; k < nbits; ++k) {
+        bool take = live && ((pi >> k) & 1ull);
+        if (__builtin_amdgcn_ballot_w64(take) == 0ull) continue;   // wave-uniform skip
+        const uint32_t* __restrict__ M = jump + (size_t)k * kXwBits * kXwWords;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+#pragma unroll
+        for (int w = 0; w < kXwWords; ++w) {
+            uint32_t word = v[w];
+            for (int b = 0; b < 32; ++b) {
+                uint32_t mask = 0u - ((word >> b) & 1u);
+                const uint32_t* row = M + (size_t)(w * 32 + b) * kXwWords;   // uniform address
+                r0 ^= row[0] & mask;
+                r1 ^= row[1] & mask;
+                r2 ^= row[2] & mask;
+                r3 ^= row[3] & mask;
+                r4 ^= row[4] & mask;
+            }
+        }
+        if (take) { v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3; v[4] = r4; }
+    }
+    if (live) {   // SoA: coalesced
+        state[0 * count + i] = d;
+        state[1 * count + i] = v[0];
+        state[2 * count + i] = v[1];
+        state[3 * count + i] = v[2];
+        state[4 * count + i] = v[3];
+        state[5 * count + i] = v[4];
+    }
+}
+
+hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long count,
+                           uint64_t seed, const uint32_t* d_jump, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    unsigned long long last = (unsigned long long)(first_pixel + count - 1);
+    int nbits = 0;
+    while (nbits < kXwJumps && (last >> nbits) != 0ull) ++nbits;
+    dim3 block(256), grid((unsigned)((count + 255) / 256));
+    hipLaunchKernelGGL(rng_init_kernel, grid, block, 0, stream, d_state, first_pixel, count,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), d_jump, nbits);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ triangle prepass
+// Per triangle, once per camera origin: the ray-independent part of
+// Triangle::collision_detection (shapes/triangle.h:69-70,81,87,92) in its own order.
+__global__ void __launch_bounds__(256)
+tri_prepass_kernel(const float* __restrict__ base, int n, float ox, float oy, float oz,
+                   float* __restrict__ rec) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* b = base + (size_t)i * kBaseFloats;
+    float v0x = b[0], v0y = b[1], v0z = b[2];
+    float v1x = b[3], v1y = b[4], v1z = b[5];
+    float v2x = b[6], v2y = b[7], v2z = b[8];
+    float e1x = v1x - v0x, e1y = v1y - v0y, e1z = v1z - v0z;       // edge1 = vertex1 - vertex0
+    float e2x = v2x - v0x, e2y = v2y - v0y, e2z = v2z - v0z;       // edge2 = vertex2 - vertex0
+    float sx = ox - v0x, sy = oy - v0y, sz = oz - v0z;             // s = r.origin() - vertex0
+    float qx = (sy * e1z - sz * e1y);                              // q = cross(s, edge1), vec3.h:113-117
+    float qy = (-(sx * e1z - sz * e1x));
+    float qz = (sx * e1y - sy * e1x);
+    float tq = e2x * qx + e2y * qy + e2z * qz;                     // dot(edge2, q)
+    float4* o = reinterpret_cast<float4*>(rec + (size_t)i * kRecFloats);
+    o[0] = make_float4(b[9], b[10], b[11], e2x);
+    o[1] = make_float4(e2y, e2z, e1x, e1y);
+    o[2] = make_float4(e1z, sx, sy, sz);
+    o[3] = make_float4(qx, qy, qz, tq);
+}
+
+hipError_t launch_tri_prepass(const float* d_base, int n_tris, const float origin[3],
+                              float* d_rec, hipStream_t stream) {
+    if (n_tris <= 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_tris + 255) / 256));
+    hipLaunchKernelGGL(tri_prepass_kernel, grid, block, 0, stream, d_base, n_tris, origin[0],
+                       origin[1], origin[2], d_rec);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ render
+struct V3 {
+    float x, y, z;
+};
+
+// unit_vector(v) = v / v.length()  (core/vec3.h:191-193,38-40,105-107): three IEEE divides.
+__device__ __forceinline__ V3 unit_vector(V3 v) {
+    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return V3{v.x / len, v.y / len, v.z / len};
+}
+
+// backgroundSky (core/render.h:41-46) given v = unit_vector(d0) already.
+__device__ __forceinline__ V3 sky_from_unit(V3 v) {
+    float t = 0.5f * (v.y + 1.0f);
+    // lerp(t, vec3(1), vec3(0.5,0.7,1.0)) = from + t*(to - from)   (vec3.h:196-198)
+    return V3{1.0f + t * (0.5f - 1.0f), 1.0f + t * (0.7f - 1.0f), 1.0f + t * (1.0f - 1.0f)};
+}
+
+// Closest hit of HitableList::collision_detection (hitable/hitable_list.h:76-91) over the
+// derived records: minimum t over all triangles that pass Triangle::collision_detection
+// (any sign of t, no range test), lowest index on ties, NaN never accepted.
+// `rec` is wave-uniform; d is this lane's twice-normalised direction.
+__device__ __forceinline__ void closest_hit_list(const float* __restrict__ rec, int n_tris,
+                                                 V3 d, float& closest, int& hit_idx) {
+    closest = FLT_MAX;   // double closest_so_far = t_max (FLT_MAX), hitable_list.h:82
+    hit_idx = -1;
+    for (int i = 0; i < n_tris; ++i) {
+        const float* __restrict__ r = rec + (size_t)i * kRecFloats;   // uniform -> scalar loads
+        const float nx = r[0], ny = r[1], nz = r[2];
+        const float e2x = r[3], e2y = r[4], e2z = r[5];
+        const float e1x = r[6], e1y = r[7], e1z = r[8];
+        const float sx = r[9], sy = r[10], sz = r[11];
+        const float qx = r[12], qy = r[13], qz = r[14];
+        const float tq = r[15];
+
+        // if (dot(r.direction(), normal) < 0) return false;            triangle.h:61
+        float dn = d.x * nx + d.y * ny + d.z * nz;
+        bool alive = !(dn < 0.0f);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+
+        // h = cross(r.direction(), edge2); a = dot(edge1, h);            triangle.h:71-72
+        float hx = (d.y * e2z - d.z * e2y);
+        float hy = (-(d.x * e2z - d.z * e2x));
+        float hz = (d.x * e2y - d.y * e2x);
+        float a = e1x * hx + e1y * hy + e1z * hz;
+        // if (a > -EPSILON && a < EPSILON) return false;                triangle.h:77 (backCulling is false)
+        alive = alive && !(a > -kTriEpsilon && a < kTriEpsilon);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+
+        float f = 1.0f / a;                     // f = 1.0 / a (double site, == fp32 IEEE divide), triangle.h:80
+        float u = f * (sx * hx + sy * hy + sz * hz);                      // triangle.h:82
+        alive = alive && !(u < 0.0f || u > 1.0f);                         // triangle.h:84
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+
+        float v = f * (d.x * qx + d.y * qy + d.z * qz);                   // triangle.h:88
+        alive = alive && !(v < 0.0f || u + v > 1.0f);                     // triangle.h:89
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+
+        float t = f * tq;                                                 // triangle.h:92
+        // hit(...) && tmp_rec.t < closest_so_far                         hitable_list.h:84
+        if (alive && t < closest) {
+            closest = t;
+            hit_idx = i;
+        }
+    }
+}
+
+// One lane = one pixel; one wavefront = an 8x8 pixel tile; one 256-thread block = 16x16.
+template <int VARIANT>
+__global__ void __launch_bounds__(256)
+render_list_kernel(RenderParams p, const float* __restrict__ rec,
+                   const float* __restrict__ shade_n, uint32_t* __restrict__ state,
+                   float* __restrict__ rgb) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);   // row inside the band
+    if (x >= p.nx || ly >= p.row_count) return;                        // render.h:109
+    const int y = p.row_begin + ly;
+    const long long pixel_index = (long long)y * p.nx + x;             // render.h:111 (global)
+    const long long si = pixel_index - p.rng_first_pixel;              // element of this band's states
+    const long long stride = p.rng_count;
+
+    Xorwow rs;
+    rs.d = state[0 * stride + si];
+    rs.v0 = state[1 * stride + si];
+    rs.v1 = state[2 * stride + si];
+    rs.v2 = state[3 * stride + si];
+    rs.v3 = state[4 * stride + si];
+    rs.v4 = state[5 * stride + si];
+
+    const CameraPOD& c = p.cam;
+    float colx = 0.0f, coly = 0.0f, colz = 0.0f;
+    const float fnx = (float)p.nx, fny = (float)p.ny;
+
+    for (int smp = 0; smp < p.samples; ++smp) {
+        float u = ((float)x + xw_uniform(rs)) / fnx;                   // render.h:116
+        float v = ((float)y + xw_uniform(rs)) / fny;                   // render.h:117
+        // get_ray(u, v, state): the lens sample comes from state[0] (render.h:118,
+        // camera.h:6-13,41).  With lens_radius == 0 only its side effect on stream 0
+        // exists; under serial-order semantics only pixel 0 observes it.
+        if (pixel_index == 0) {
+            float px, py;
+            do {
+                px = 2.0f * xw_uniform(rs) - 1.0f;
+                py = 2.0f * xw_uniform(rs) - 1.0f;
+            } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);          // dot(p,p) with p.z = 2*0-0
+        }
+        // direction = lower_left_corner + s*horizontal + t*vertical - origin - offset, offset = 0
+        V3 d0;
+        d0.x = ((c.llc[0] + u * c.horizontal[0]) + v * c.vertical[0]) - c.origin[0];
+        d0.y = ((c.llc[1] + u * c.horizontal[1]) + v * c.vertical[1]) - c.origin[1];
+        d0.z = ((c.llc[2] + u * c.horizontal[2]) + v * c.vertical[2]) - c.origin[2];
+
+        // world list Transform then triangle Transform: ScaleRay normalises twice
+        // (transform.h:50-54 via hitable.h:34 at both levels).
+        V3 d1 = unit_vector(d0);
+        V3 d2 = unit_vector(d1);
+
+        float closest;
+        int hit_idx;
+        closest_hit_list(rec, p.n_tris, d2, closest, hit_idx);
+
+        V3 sky = sky_from_unit(d1);                                    // backgroundSky(r.direction())
+        if (hit_idx >= 0) {                                            // LambertShade, render.h:75-83
+            // Lambertian::scatter -> random_in_unit_sphere: only the draws matter (material.h:11-19,66)
+            float sxr, syr, szr;
+            do {
+                sxr = 2.0f * xw_uniform(rs) - 1.0f;
+                syr = 2.0f * xw_uniform(rs) - 1.0f;
+                szr = 2.0f * xw_uniform(rs) - 1.0f;
+            } while (sxr * sxr + syr * syr + szr * szr >= 1.0f);
+            const float* sn = shade_n + (size_t)hit_idx * 3;           // normal after both rotate() calls
+            float t = d0.x * sn[0] + d0.y * sn[1] + d0.z * sn[2];      // dot(r.direction(), rec.normal)
+            if (t < 0.0f) t = 0.0f;
+            // attenuation * t * backgroundSky(...) * 0.2 + emitted
+            colx += 0.2f * ((t * p.albedo[0]) * sky.x) + 0.0f;
+            coly += 0.2f * ((t * p.albedo[1]) * sky.y) + 0.0f;
+            colz += 0.2f * ((t * p.albedo[2]) * sky.z) + 0.0f;
+        } else {
+            colx += sky.x;                                             // render.h:85
+            coly += sky.y;
+            colz += sky.z;
+        }
+    }
+
+    // col /= float(ns): k = float(1.0 / double(ns)); col *= k                vec3.h:182-189
+    float k = (float)(1.0 / (double)(float)p.samples);
+    colx *= k;
+    coly *= k;
+    colz *= k;
+    colx = sqrtf(colx);                                                // render.h:124-126
+    coly = sqrtf(coly);
+    colz = sqrtf(colz);
+    // clip(col): if (f > 1) 1 else if (f < 0) 0 else f (NaN passes through)   vec3.h:119-131
+    colx = (colx > 1.0f) ? 1.0f : ((colx < 0.0f) ? 0.0f : colx);
+    coly = (coly > 1.0f) ? 1.0f : ((coly < 0.0f) ? 0.0f : coly);
+    colz = (colz > 1.0f) ? 1.0f : ((colz < 0.0f) ? 0.0f : colz);
+
+    const size_t o = ((size_t)ly * p.nx + x) * 3;
+    rgb[o + 0] = colx;
+    rgb[o + 1] = coly;
+    rgb[o + 2] = colz;
+
+    state[0 * stride + si] = rs.d;
+    state[1 * stride + si] = rs.v0;
+    state[2 * stride + si] = rs.v1;
+    state[3 * stride + si] = rs.v2;
+    state[4 * stride + si] = rs.v3;
+    state[5 * stride + si] = rs.v4;
+}
+
+hipError_t launch_render(const RenderParams& p, const float* d_rec, const float* d_shade_n,
+                         uint32_t* d_state, float* d_rgb, int variant, hipStream_t stream) {
+    if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
+    dim3 block(256);
+    dim3 grid((unsigned)((p.nx + 15) / 16), (unsigned)((p.row_count + 15) / 16));
+    (void)variant;
+    hipLaunchKernelGGL(render_list_kernel<0>, grid, block, 0, stream, p, d_rec, d_shade_n, d_state,
+                       d_rgb);
+    return hipGetLastError();
+}
+
+}  // namespace crt

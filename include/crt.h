@@ -1,0 +1,167 @@
+/*
+ * crt.h — C ABI of libcrt_hip.so, the MI355X (gfx950) drop-in for the list-render path of
+ * chocorone/CudaRaytracer.
+ *
+ * The reference has no plugin/FFI layer: the path is a __global__ function and a handful
+ * of host functions in headers compiled into one executable.  Each entry point below
+ * replaces one of those host functions / kernels; the citation after "replaces:" is the
+ * reference interface (paths relative to CudaTest/src of the reference tree).
+ *
+ * Conventions
+ *   - plain C types only; device buffers are passed as void* / float* device pointers
+ *   - int return: 0 = CRT_OK, negative = error (never exit(), unlike the reference's
+ *     checkCudaErrors / CHECK, core/deviceManage.h:3-17); crt_last_error() gives the text
+ *   - the library owns device memory behind opaque handles; the caller owns every buffer
+ *     it passes in (host or device)
+ *   - thread-compatible: one handle set per host thread; every call works on the HIP
+ *     device that is current when the handle was created
+ *   - there is NO CPU fallback: every compute entry point fails with CRT_ERR_NO_DEVICE
+ *     when no HIP device is usable
+ */
+#ifndef CRT_H
+#define CRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_ABI_VERSION 1
+
+enum {
+    CRT_OK = 0,
+    CRT_ERR_INVALID = -1,     /* bad argument (null pointer, non-positive size, index out of range) */
+    CRT_ERR_NO_DEVICE = -2,   /* no usable HIP device / HIP runtime error at init */
+    CRT_ERR_HIP = -3,         /* a HIP call or kernel launch failed */
+    CRT_ERR_IO = -4,          /* file could not be read / written */
+    CRT_ERR_UNSUPPORTED = -5, /* input whose reference behaviour is undefined (see crt_render_rows) */
+    CRT_ERR_NOMEM = -6
+};
+
+/* replaces: class Camera's data members, core/camera.h:46-52 (88 bytes, same order). */
+typedef struct crt_camera {
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float origin[3];
+    float x[3], y[3], z[3];
+    float lens_radius;
+} crt_camera;
+
+/* Opaque handles. */
+typedef struct crt_scene crt_scene; /* replaces: HitableList** world (kernel.cu:78-90) */
+typedef struct crt_rng crt_rng;     /* replaces: curandState* curand_state (kernel.cu:69-71) */
+
+/* ---- library ------------------------------------------------------------------- */
+
+int crt_abi_version(void);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *crt_last_error(void);
+/* Number of visible HIP devices (0 when the runtime is unusable). Never fails. */
+int crt_device_count(void);
+
+/* ---- camera -------------------------------------------------------------------- */
+
+/* replaces: Camera::Camera (core/camera.h:18-38) as called by create_camera
+ * (createScene.h:142-154, init_camera :156-165).  Host-side; tan() is evaluated with the
+ * host libm so the device never calls a transcendental. */
+void crt_camera_make(crt_camera *out, const float lookfrom[3], const float lookat[3],
+                     const float vup[3], float vfov, float aspect, float aperture,
+                     float focus_dist);
+
+/* ---- scene --------------------------------------------------------------------- */
+
+/* replaces: create_FBXMesh + add_mesh_withNormal (createScene.h:175-210).
+ * points:  n_points x 3 floats.  idx3f: n_tris x 3 floats — the reference stores vertex
+ * indices as float triplets (vec3* idxVertex); triangle i uses
+ * {points[int(idx[2])-base], points[int(idx[1])-base], points[int(idx[0])-base]}
+ * (reversed winding, createScene.h:183).  face_normals: n_tris x 3 floats kept as the
+ * stored normal (6-argument Triangle ctor, shapes/triangle.h:21-29), or NULL to apply the
+ * 5-argument ctor rule unit_vector(cross(v1-v0, v2-v0)) (shapes/triangle.h:8-19).
+ * albedo: the single Lambertian ConstantTexture colour (createScene.h:180).
+ * Every triangle gets Transform(0,0,1) and EPSILON 1e-6 as in the reference.
+ * All arrays are host pointers.  Returns NULL on error. */
+crt_scene *crt_scene_from_mesh(const float *points, int n_points, const float *idx3f,
+                               int n_tris, const float *face_normals, int index_base,
+                               const float albedo[3]);
+
+/* replaces: parseObjByName (Loader/obj_loader.h:20-111) + computeMean/centering
+ * (:120-133) + the historic `points[i] *= 100.0` scale (:164) + the scene pack above with
+ * index_base 1 and computed normals.  Only `v x y z` and `f a b c` records are read, as
+ * in the reference. */
+crt_scene *crt_scene_from_obj(const char *path, float scale, const float albedo[3]);
+
+int crt_scene_triangle_count(const crt_scene *scene);
+void crt_scene_free(crt_scene *scene);
+
+/* Host-side OBJ parse only (same rules as crt_scene_from_obj, before scaling): call with
+ * NULL buffers to get the counts, then with buffers of n_points*3 / n_tris*3 floats. */
+int crt_parse_obj(const char *path, float *points, float *idx3f, int *n_points, int *n_tris);
+
+/* ---- RNG ----------------------------------------------------------------------- */
+
+/* replaces: cudaMallocManaged(curandState[nx*ny]) + SetCurandState -> random_init
+ * (kernel.cu:69-71, core/deviceManage.h:120-136).  Creates device-resident XORWOW states
+ * for the `count` pixels [first_pixel, first_pixel+count) of an image and initialises
+ * them like curand_init(seed, pixel_index, 0, &state[pixel_index]).  A rank that renders
+ * a row band passes first_pixel = row_begin*nx, count = rows*nx. */
+crt_rng *crt_rng_create(int64_t first_pixel, int64_t count, uint64_t seed);
+/* Re-run the initialisation (same as a fresh crt_rng_create). */
+int crt_rng_reset(crt_rng *rng, uint64_t seed);
+/* Copy states to the host as count x 6 uint32 {d, v0..v4} (test/diagnostic use). */
+int crt_rng_export(const crt_rng *rng, uint32_t *out6);
+void crt_rng_free(crt_rng *rng);
+
+/* ---- render -------------------------------------------------------------------- */
+
+/* replaces: the `render` kernel (core/render.h:105-129) and everything it calls —
+ * Camera::get_ray, Hitable::hit / Transform::TransformRay, HitableList::
+ * collision_detection, Triangle::collision_detection, Lambertian::scatter,
+ * LambertShade, backgroundSky — for rows [row_begin, row_begin+row_count) of an
+ * nx x ny image.
+ *   d_rgb:  DEVICE pointer to row_count*nx*3 floats (AoS float3 like vec3* colorBuffer);
+ *           element 0 is pixel (x=0, y=row_begin); row 0 of the image is its bottom row.
+ *   rng:    states for exactly those pixels (first_pixel = row_begin*nx); advanced in
+ *           place, so consecutive calls continue the streams like the reference's frame
+ *           loop (core/render.h:174-186).
+ *   max_depth, frame_index: accepted for signature parity; dead on this path
+ *           (LambertShade never recurses, core/render.h:70-87,120).
+ *   stream: hipStream_t (NULL = default stream).  The call only enqueues work.
+ * CRT_ERR_UNSUPPORTED when camera->lens_radius != 0: the reference then reads lens samples
+ * from state[0] in every thread concurrently (core/render.h:118), a data race with no
+ * defined result. */
+int crt_render_rows(const crt_scene *scene, const crt_camera *camera, crt_rng *rng, int nx,
+                    int ny, int samples, int max_depth, int frame_index, int row_begin,
+                    int row_count, float *d_rgb, void *stream);
+
+/* replaces: one frame of renderListAnimation (core/render.h:159-189): allocates device
+ * RNG states and a device colour buffer, renders the full image on the current device,
+ * synchronises and copies nx*ny*3 floats to the HOST buffer rgb_out. */
+int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
+               const crt_scene *scene, const crt_camera *camera, uint64_t seed,
+               float *rgb_out);
+
+/* Kernel selection (diagnostics / A-B benchmarking): 0 = default. Returns previous. */
+int crt_set_kernel_variant(int variant);
+
+/* Duration in milliseconds of the last crt_render_rows main kernel launched through this
+ * library on the calling thread, measured with HIP events on the launch stream.
+ * Synchronises on that stream.  Negative on error. */
+float crt_last_kernel_ms(void);
+
+/* ---- output -------------------------------------------------------------------- */
+
+/* replaces: WritePng's conversion loop (core/render.h:137-146): vertical flip,
+ * (unsigned char)(255.99 * c), alpha 255.  rgb: host nx*ny*3 floats; rgba: nx*ny*4 bytes. */
+void crt_to_rgba8(const float *rgb, int nx, int ny, unsigned char *rgba);
+
+/* replaces: WritePng (core/render.h:135-157): the conversion above, then an RGBA8 PNG at
+ * `path` (the reference calls stbi_write_png(path, nx, ny, 4, rgb, 0), :153; this library
+ * carries its own zlib-based PNG encoder — same pixels, not the same compressed bytes). */
+int crt_write_png(const char *path, int nx, int ny, const float *rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_H */

@@ -1,0 +1,574 @@
+/*
+ * crt_oracle.c — CPU oracle (TEST INFRASTRUCTURE, PARITY UNPINNED; see crt_oracle.h).
+ *
+ * Plain-C restatement of the reference's list-render path.  Structure mirrors the
+ * reference on purpose (per-object Transform, rotate() with its sin/cos, the virtual
+ * hit() wrapper applied at the world list AND at every triangle, double-typed sites),
+ * so that every line can be checked against the file:line it cites.  Paths are relative
+ * to /root/reference/CudaTest/src.
+ *
+ * Build: gcc -std=c11 -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile).
+ */
+#include "crt_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ core/vec3.h */
+
+static o_vec3 v3(float a, float b, float c) { o_vec3 r; r.e[0] = a; r.e[1] = b; r.e[2] = c; return r; } /* vec3.h:13-15 */
+static o_vec3 v1(float a) { return v3(a, a, a); }                                                      /* vec3.h:10-12 */
+
+static o_vec3 add(o_vec3 a, o_vec3 b) { return v3(a.e[0] + b.e[0], a.e[1] + b.e[1], a.e[2] + b.e[2]); } /* vec3.h:73-75 */
+static o_vec3 sub(o_vec3 a, o_vec3 b) { return v3(a.e[0] - b.e[0], a.e[1] - b.e[1], a.e[2] - b.e[2]); } /* vec3.h:77-79 */
+static o_vec3 mulv(o_vec3 a, o_vec3 b) { return v3(a.e[0] * b.e[0], a.e[1] * b.e[1], a.e[2] * b.e[2]); } /* vec3.h:89-91 */
+static o_vec3 muls(float t, o_vec3 v) { return v3(t * v.e[0], t * v.e[1], t * v.e[2]); }               /* vec3.h:93-99 (both orders compute t*v.e[i]) */
+static o_vec3 divv(o_vec3 a, o_vec3 b) { return v3(a.e[0] / b.e[0], a.e[1] / b.e[1], a.e[2] / b.e[2]); } /* vec3.h:101-103 */
+static o_vec3 divs(o_vec3 v, float t) { return v3(v.e[0] / t, v.e[1] / t, v.e[2] / t); }               /* vec3.h:105-107 */
+
+static float dot(o_vec3 a, o_vec3 b) { return a.e[0] * b.e[0] + a.e[1] * b.e[1] + a.e[2] * b.e[2]; }   /* vec3.h:109-111 */
+static o_vec3 cross(o_vec3 a, o_vec3 b) {                                                              /* vec3.h:113-117 */
+    return v3((a.e[1] * b.e[2] - a.e[2] * b.e[1]),
+              (-(a.e[0] * b.e[2] - a.e[2] * b.e[0])),
+              (a.e[0] * b.e[1] - a.e[1] * b.e[0]));
+}
+static float length(o_vec3 v) { return sqrtf(v.e[0] * v.e[0] + v.e[1] * v.e[1] + v.e[2] * v.e[2]); }   /* vec3.h:38-40 (sqrt(float) -> float overload) */
+static float squared_length(o_vec3 v) { return v.e[0] * v.e[0] + v.e[1] * v.e[1] + v.e[2] * v.e[2]; }  /* vec3.h:42-44 */
+static float sum3(o_vec3 v) { return v.e[0] + v.e[1] + v.e[2]; }                                       /* vec3.h:68-71 */
+static o_vec3 unit_vector(o_vec3 v) { return divs(v, length(v)); }                                     /* vec3.h:191-193 */
+static o_vec3 lerp3(float t, o_vec3 from, o_vec3 to) { return add(from, muls(t, sub(to, from))); }      /* vec3.h:196-198 */
+
+static float clip_single(float f, int min, int max) {                                                  /* vec3.h:119-123 */
+    if (f > max) return max;
+    else if (f < min) return min;
+    return f;
+}
+static o_vec3 clip(o_vec3 v) {                                                                         /* vec3.h:125-131, min=0 max=1 */
+    o_vec3 vr = v3(0, 0, 0);
+    vr.e[0] = clip_single(v.e[0], 0, 1);
+    vr.e[1] = clip_single(v.e[1], 0, 1);
+    vr.e[2] = clip_single(v.e[2], 0, 1);
+    return vr;
+}
+static o_vec3 div_assign_s(o_vec3 v, float t) {                                                        /* vec3.h:182-189 */
+    float k = 1.0 / t; /* double site: (float)(1.0 / (double)t) */
+    return v3(v.e[0] * k, v.e[1] * k, v.e[2] * k);
+}
+
+static o_vec3 rotate(o_vec3 origin, o_vec3 rotation) {                                                 /* vec3.h:200-217 */
+    float radiansX = (M_PI / 180.) * rotation.e[0];
+    float sin_X = sinf(radiansX);
+    float cos_X = cosf(radiansX);
+    float radiansY = (M_PI / 180.) * rotation.e[1];
+    float sin_Y = sinf(radiansY);
+    float cos_Y = cosf(radiansY);
+    float radiansZ = -(M_PI / 180.) * rotation.e[2];
+    float sin_Z = sinf(radiansZ);
+    float cos_Z = cosf(radiansZ);
+
+    o_vec3 rotate0 = v3(cos_Y * cos_Z, -cos_Y * sin_Z, sin_Y);
+    o_vec3 rotate1 = v3(sin_X * sin_Y * cos_Z + cos_X * sin_Z, -sin_X * sin_Y * sin_Z + cos_X * cos_Z, -sin_X * cos_Y);
+    o_vec3 rotate2 = v3(-cos_X * sin_Y * cos_Z + sin_X * sin_Z, cos_X * sin_Y * sin_Z + sin_X * cos_Z, cos_X * cos_Y);
+
+    return v3(sum3(mulv(origin, rotate0)), sum3(mulv(origin, rotate1)), sum3(mulv(origin, rotate2)));
+}
+
+/* ------------------------------------------------------------------ core/ray.h */
+
+typedef struct { float _time; o_vec3 _origin; o_vec3 _direction; } o_ray;                              /* ray.h:20-22 */
+static o_ray make_ray(o_vec3 o, o_vec3 d, float t) { o_ray r; r._time = t; r._origin = o; r._direction = d; return r; } /* ray.h:11 */
+static o_vec3 point_at_t(const o_ray *r, float t) { return add(r->_origin, muls(t, r->_direction)); }  /* ray.h:18 */
+
+/* ------------------------------------------------------------------ cuRAND XORWOW
+ * Third-party arithmetic that is NOT in /root/reference: cuRAND device API of CUDA
+ * Toolkit 12.2 (CudaTest/CudaTest.vcxproj:33), curand_kernel.h.  Restated from the
+ * published algorithm: Marsaglia's xorwow recurrence + Weyl sequence, cuRAND's seed
+ * scrambling constants, and the 2^67-step subsequence skip expressed as powers of the
+ * GF(2) transition matrix of the xorshift part.  No known-answer vector exists offline:
+ * PARITY UNPINNED at this boundary. */
+
+unsigned int o_curand(o_curand_state *s) {                                /* curand_kernel.h: curand(curandStateXORWOW_t*) */
+    unsigned int t;
+    t = (s->v[0] ^ (s->v[0] >> 2));
+    s->v[0] = s->v[1];
+    s->v[1] = s->v[2];
+    s->v[2] = s->v[3];
+    s->v[3] = s->v[4];
+    s->v[4] = (s->v[4] ^ (s->v[4] << 4)) ^ (t ^ (t << 1));
+    s->d += 362437;
+    return s->v[4] + s->d;
+}
+
+float o_curand_uniform(o_curand_state *s) {                               /* curand_kernel.h: _curand_uniform */
+    unsigned int x = o_curand(s);
+    const float CURAND_2POW32_INV = 2.3283064e-10f;
+    return x * CURAND_2POW32_INV + (CURAND_2POW32_INV / 2.0f);
+}
+
+/* 160x160 GF(2) matrix, row-vector convention (cuRAND's __curand_matvec): row b is the
+ * image of state bit b (word b/32, bit b%32). */
+#define XW_N 5
+#define XW_BITS (XW_N * 32)
+typedef struct { unsigned int row[XW_BITS][XW_N]; } xw_matrix;
+
+static void xw_step_words(unsigned int v[XW_N]) {      /* the xorshift part of curand() without the Weyl sequence */
+    unsigned int t = (v[0] ^ (v[0] >> 2));
+    v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = v[4];
+    v[4] = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+}
+
+static void xw_matvec(const unsigned int vec[XW_N], const xw_matrix *m, unsigned int out[XW_N]) { /* __curand_matvec */
+    unsigned int r[XW_N] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < XW_N; i++)
+        for (int j = 0; j < 32; j++)
+            if (vec[i] & (1u << j))
+                for (int k = 0; k < XW_N; k++) r[k] ^= m->row[i * 32 + j][k];
+    for (int k = 0; k < XW_N; k++) out[k] = r[k];
+}
+
+static void xw_matmat(xw_matrix *dst, const xw_matrix *a, const xw_matrix *b) { /* dst = a*b : apply a, then b */
+    xw_matrix *tmp = (xw_matrix *)malloc(sizeof(xw_matrix));
+    for (int r = 0; r < XW_BITS; r++) xw_matvec(a->row[r], b, tmp->row[r]);
+    memcpy(dst, tmp, sizeof(xw_matrix));
+    free(tmp);
+}
+
+static void xw_one_step_matrix(xw_matrix *m) {
+    for (int b = 0; b < XW_BITS; b++) {
+        unsigned int v[XW_N] = {0, 0, 0, 0, 0};
+        v[b / 32] = 1u << (b % 32);
+        xw_step_words(v);
+        for (int k = 0; k < XW_N; k++) m->row[b][k] = v[k];
+    }
+}
+
+/* Byte-sliced application table for one matrix (pure speed-up of xw_matvec). */
+typedef struct { unsigned int t[XW_N * 4][256][XW_N]; } xw_table;
+
+static void xw_build_table(const xw_matrix *m, xw_table *tb) {
+    for (int byte = 0; byte < XW_N * 4; byte++)
+        for (int val = 0; val < 256; val++) {
+            unsigned int r[XW_N] = {0, 0, 0, 0, 0};
+            for (int bit = 0; bit < 8; bit++)
+                if (val & (1 << bit))
+                    for (int k = 0; k < XW_N; k++) r[k] ^= m->row[byte * 8 + bit][k];
+            for (int k = 0; k < XW_N; k++) tb->t[byte][val][k] = r[k];
+        }
+}
+
+static void xw_apply_table(unsigned int v[XW_N], const xw_table *tb) {
+    unsigned int r[XW_N] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < XW_N; w++)
+        for (int b = 0; b < 4; b++) {
+            const unsigned int *e = tb->t[w * 4 + b][(v[w] >> (8 * b)) & 0xff];
+            for (int k = 0; k < XW_N; k++) r[k] ^= e[k];
+        }
+    for (int k = 0; k < XW_N; k++) v[k] = r[k];
+}
+
+/* cuRAND walks the skip count two bits at a time (PRECALC_BLOCK_SIZE 2): digit i of the
+ * count applies M_i = base^(4^i) that many (0..3) times.  seq tables: base = T^(2^67)
+ * (_skipahead_sequence_scratch); offset tables: base = T (_skipahead_scratch). */
+#define XW_DIGITS 32
+static xw_table *g_seq_tab[XW_DIGITS];
+static xw_table *g_off_tab[XW_DIGITS];
+static xw_matrix *g_seq_mat[XW_DIGITS];
+static xw_matrix *g_off_mat[XW_DIGITS];
+
+static void xw_ensure(int digit, int seq) {
+    xw_matrix **mat = seq ? g_seq_mat : g_off_mat;
+    xw_table **tab = seq ? g_seq_tab : g_off_tab;
+    if (tab[digit]) return;
+    if (!mat[0]) {
+        mat[0] = (xw_matrix *)malloc(sizeof(xw_matrix));
+        xw_one_step_matrix(mat[0]);
+        if (seq)
+            for (int i = 0; i < 67; i++) xw_matmat(mat[0], mat[0], mat[0]); /* T^(2^67) */
+    }
+    for (int i = 1; i <= digit; i++) {
+        if (mat[i]) continue;
+        mat[i] = (xw_matrix *)malloc(sizeof(xw_matrix));
+        xw_matmat(mat[i], mat[i - 1], mat[i - 1]); /* ^2 */
+        xw_matmat(mat[i], mat[i], mat[i]);         /* ^4 */
+    }
+    for (int i = 0; i <= digit; i++) {
+        if (tab[i]) continue;
+        tab[i] = (xw_table *)malloc(sizeof(xw_table));
+        xw_build_table(mat[i], tab[i]);
+    }
+}
+
+static void xw_skip(unsigned int v[XW_N], unsigned long long count, int seq) {
+    unsigned long long p = count;
+    int digit = 0;
+    while (p) {
+        unsigned int reps = (unsigned int)(p & 3);
+        if (reps) {
+            xw_ensure(digit, seq);
+            for (unsigned int t = 0; t < reps; t++) xw_apply_table(v, (seq ? g_seq_tab : g_off_tab)[digit]);
+        }
+        p >>= 2;
+        digit++;
+    }
+}
+
+void o_curand_init(unsigned long long seed, unsigned long long subsequence,
+                   unsigned long long offset, o_curand_state *state) {     /* curand_kernel.h: _curand_init_scratch */
+    unsigned int s0 = ((unsigned int)seed) ^ 0xaad26b49U;
+    unsigned int s1 = (unsigned int)(seed >> 32) ^ 0xf7dcefddU;
+    unsigned int t0 = 1099087573U * s0;
+    unsigned int t1 = 2591861531U * s1;
+    state->d = 6615241 + t1 + t0;
+    state->v[0] = 123456789U + t0;
+    state->v[1] = 362436069U ^ t0;
+    state->v[2] = 521288629U + t1;
+    state->v[3] = 88675123U ^ t1;
+    state->v[4] = 5783321U + t0;
+    xw_skip(state->v, subsequence, 1); /* 2^67 steps per subsequence; d unchanged (2^67*362437 == 0 mod 2^32) */
+    xw_skip(state->v, offset, 0);
+    state->d += 362437 * (unsigned int)offset;
+}
+
+void o_set_curand_state_range(o_curand_state *state, long long first, long long count,
+                              unsigned long long seed) {
+    for (long long i = 0; i < count; i++)
+        o_curand_init(seed, (unsigned long long)(first + i), 0, &state[i]);     /* deviceManage.h:127 */
+}
+
+void o_set_curand_state(o_curand_state *state, int nx, int ny, unsigned long long seed) { /* deviceManage.h:120-136 */
+    o_set_curand_state_range(state, 0, (long long)nx * ny, seed);
+}
+
+/* ------------------------------------------------------------------ core/camera.h */
+
+static o_vec3 random_in_unit_disk(o_curand_state *state) {                /* camera.h:6-13 */
+    o_vec3 p;
+    do {
+        /* constructor-argument order fixed to source order (1st draw = x) */
+        float a = o_curand_uniform(state);
+        float b = o_curand_uniform(state);
+        p = sub(muls(2.0f, v3(a, b, 0)), v3(1, 1, 0));
+    } while (dot(p, p) >= 1.0f);
+    return p;
+}
+
+void o_camera_init(o_camera *c, const float lookfrom_[3], const float lookat_[3],
+                   const float vup_[3], float vfov, float aspect, float aperture,
+                   float focus_dist) {                                    /* camera.h:18-38 */
+    o_vec3 lookfrom = v3(lookfrom_[0], lookfrom_[1], lookfrom_[2]);
+    o_vec3 lookat = v3(lookat_[0], lookat_[1], lookat_[2]);
+    o_vec3 vup = v3(vup_[0], vup_[1], vup_[2]);
+    c->lens_radius = aperture / 2.0f;
+    float theta = vfov * M_PI / 180.0f; /* double product and quotient, rounded once to float */
+    float half_height = tanf(theta / 2.0f);
+    float half_width = half_height * aspect;
+
+    c->origin = lookfrom;
+    c->z = unit_vector(sub(lookfrom, lookat));
+    c->x = unit_vector(cross(vup, c->z));
+    c->y = cross(c->z, c->x);
+
+    c->lower_left_corner = sub(sub(sub(c->origin, muls(half_width * focus_dist, c->x)),
+                                   muls(half_height * focus_dist, c->y)),
+                               muls(focus_dist, c->z));
+    c->horizontal = muls(2.0f * half_width * focus_dist, c->x);
+    c->vertical = muls(2.0f * half_height * focus_dist, c->y);
+}
+
+static o_ray get_ray(const o_camera *c, float s, float t, o_curand_state *state) { /* camera.h:40-44 */
+    o_vec3 rd = muls(c->lens_radius, random_in_unit_disk(state));
+    o_vec3 offset = add(muls(rd.e[0], c->x), muls(rd.e[1], c->y));
+    return make_ray(add(c->origin, offset),
+                    sub(sub(add(add(c->lower_left_corner, muls(s, c->horizontal)), muls(t, c->vertical)), c->origin), offset),
+                    0.0f);
+}
+
+/* ------------------------------------------------------------------ hitable/transform.h */
+
+static o_ray ScaleRay(const o_transform *tr, const o_ray *r) {            /* transform.h:50-54 */
+    o_vec3 dir = divv(r->_direction, tr->scale);
+    return make_ray(r->_origin, unit_vector(dir), r->_time * length(dir));
+}
+static o_ray RotateRay(const o_transform *tr, const o_ray *r) {           /* transform.h:43-48 */
+    return make_ray(rotate(r->_origin, tr->rotation), rotate(r->_direction, tr->rotation), r->_time);
+}
+static o_ray TranslateRay(const o_transform *tr, const o_ray *r) {        /* transform.h:38-41 */
+    return make_ray(sub(r->_origin, tr->position), r->_direction, r->_time);
+}
+static o_ray TransformRay(const o_transform *tr, const o_ray *r) {        /* transform.h:11-14 */
+    o_ray a = ScaleRay(tr, r);
+    o_ray b = RotateRay(tr, &a);
+    return TranslateRay(tr, &b);
+}
+
+/* ------------------------------------------------------------------ hitable/hitable.h */
+
+typedef struct { float t, u, v; o_vec3 p, normal; int mat_set; } o_hitrec; /* hitable.h:11-18 */
+
+/* shapes/triangle.h:57-100 */
+static int triangle_collision_detection(const o_triangle *tri, const o_ray *r, float t_min, float t_max, o_hitrec *rec) {
+    (void)t_min; (void)t_max; /* ignored by the reference too */
+    if (dot(r->_direction, tri->normal) < 0) return 0;
+    o_vec3 vertex0 = tri->vertices[0];
+    o_vec3 vertex1 = tri->vertices[1];
+    o_vec3 vertex2 = tri->vertices[2];
+
+    o_vec3 edge1, edge2, h, s, q;
+    float a, f, u, v;
+
+    edge1 = sub(vertex1, vertex0);
+    edge2 = sub(vertex2, vertex0);
+    h = cross(r->_direction, edge2);
+    a = dot(edge1, h);
+
+    if (a < tri->EPSILON && tri->backCulling) return 0;
+    if (a > -tri->EPSILON && a < tri->EPSILON) return 0;
+
+    f = 1.0 / a; /* double site */
+    s = sub(r->_origin, vertex0);
+    u = f * dot(s, h);
+
+    if (u < 0.0 || u > 1.0) return 0;
+
+    q = cross(s, edge1);
+    v = f * dot(r->_direction, q);
+    if (v < 0.0 || u + v > 1.0) return 0;
+
+    float t = f * dot(edge2, q);
+
+    rec->t = t;
+    rec->p = point_at_t(r, rec->t);
+    rec->normal = tri->normal;
+    rec->mat_set = 1;
+    return 1;
+}
+
+static int triangle_hit(const o_triangle *tri, const o_ray *r, float t_min, float t_max, o_hitrec *rec) { /* hitable.h:29-38 */
+    o_ray tr = TransformRay(&tri->transform, r);
+    int flag = triangle_collision_detection(tri, &tr, t_min, t_max, rec);
+    rec->normal = rotate(rec->normal, tri->transform.rotation); /* also on a miss */
+    return flag;
+}
+
+static int list_collision_detection(const o_world *w, const o_ray *r, float t_min, float t_max, o_hitrec *rec, int *index) { /* hitable_list.h:76-91 */
+    o_hitrec tmp_rec;
+    memset(&tmp_rec, 0, sizeof tmp_rec); /* reference leaves it uninitialised; only read after a write on accepted hits */
+    int hit_anything = 0;
+    double closest_so_far = t_max;
+    for (int i = 0; i < w->list_size; i++) {
+        if (triangle_hit(&w->list[i], r, t_min, (float)closest_so_far, &tmp_rec) && tmp_rec.t < closest_so_far) {
+            hit_anything = 1;
+            closest_so_far = tmp_rec.t;
+            *rec = tmp_rec;
+            if (index) *index = i;
+        }
+    }
+    return hit_anything;
+}
+
+static int world_hit(const o_world *w, const o_ray *r, float t_min, float t_max, o_hitrec *rec, int *index) { /* hitable.h:29-38 on the list */
+    o_ray tr = TransformRay(&w->transform, r);
+    int flag = list_collision_detection(w, &tr, t_min, t_max, rec, index);
+    rec->normal = rotate(rec->normal, w->transform.rotation);
+    return flag;
+}
+
+int o_world_hit(const o_world *world, const float origin[3], const float direction[3],
+                float *t_out, int *index_out, float normal_out[3]) {
+    o_ray r = make_ray(v3(origin[0], origin[1], origin[2]), v3(direction[0], direction[1], direction[2]), 0.0f);
+    o_hitrec rec;
+    memset(&rec, 0, sizeof rec);
+    int idx = -1;
+    int flag = world_hit(world, &r, 0.001f, FLT_MAX, &rec, &idx);
+    if (t_out) *t_out = rec.t;
+    if (index_out) *index_out = flag ? idx : -1;
+    if (normal_out) { normal_out[0] = rec.normal.e[0]; normal_out[1] = rec.normal.e[1]; normal_out[2] = rec.normal.e[2]; }
+    return flag;
+}
+
+/* ------------------------------------------------------------------ material/material.h */
+
+static o_vec3 random_in_unit_sphere(o_curand_state *state) {              /* material.h:11-19 */
+    o_vec3 p;
+    do {
+        /* constructor-argument order fixed to source order (x, y, z = 1st, 2nd, 3rd draw) */
+        float a = o_curand_uniform(state);
+        float b = o_curand_uniform(state);
+        float c = o_curand_uniform(state);
+        p = sub(muls(2.0, v3(a, b, c)), v3(1, 1, 1)); /* 2.0 converts to float 2.0f at the call (vec3.h:93) */
+    } while (squared_length(p) >= 1.0f);
+    return p;
+}
+
+static int lambertian_scatter(const o_world *w, const o_ray *r_in, const o_hitrec *rec,
+                              o_vec3 *attenuation, o_ray *scattered, o_curand_state *state) { /* material.h:61-71 */
+    o_vec3 target = add(add(rec->p, rec->normal), random_in_unit_sphere(state));
+    *scattered = make_ray(rec->p, sub(target, rec->p), r_in->_time);
+    *attenuation = w->albedo; /* ConstantTexture::value, texture.h:17-19 */
+    return 1;
+}
+
+/* ------------------------------------------------------------------ core/render.h */
+
+static o_vec3 backgroundSky(o_vec3 d) {                                   /* render.h:41-46 */
+    o_vec3 v = unit_vector(d);
+    float t = 0.5f * (v.e[1] + 1.0f);
+    return lerp3(t, v1(1), v3(0.5f, 0.7f, 1.0f));
+}
+
+static o_vec3 LambertShade(const o_ray *r, const o_world *world, int depth, o_curand_state *state, int frameIndex) { /* render.h:70-87 */
+    (void)depth; (void)frameIndex;
+    o_hitrec rec;
+    memset(&rec, 0, sizeof rec);
+    if (world_hit(world, r, 0.001, FLT_MAX, &rec, NULL)) {
+        o_ray scattered;
+        o_vec3 attenuation;
+        o_vec3 emitted = v3(0, 0, 0); /* Material::emitted, material.h:49-53 */
+        lambertian_scatter(world, r, &rec, &attenuation, &scattered, state);
+        float t = dot(r->_direction, rec.normal);
+        if (t < 0) t = 0;
+        return add(muls(0.2, mulv(muls(t, attenuation), backgroundSky(r->_direction))), emitted);
+    } else {
+        return backgroundSky(r->_direction);
+    }
+}
+
+void o_render_window(float *colorBuffer, const o_world *world, const o_camera *camera,
+                     o_curand_state *state, int nx, int ny, int samples, int max_depth,
+                     int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
+    /* render.h:105-129, one "thread" after another in pixel_index order */
+    for (int y = row_begin; y < row_end; y++)
+        for (int x = col_begin; x < col_end; x++) {
+            if ((x >= nx) || (y >= ny)) continue;
+            int pixel_index = y * nx + x;
+            int ns = samples;
+            o_vec3 col = v3(0, 0, 0);
+            for (int i = 0; i < ns; i++) {
+                float u = (float)(x + o_curand_uniform(&state[pixel_index])) / (float)nx;
+                float v = (float)(y + o_curand_uniform(&state[pixel_index])) / (float)ny;
+                o_ray r = get_ray(camera, u, v, state); /* base pointer: &state[0], render.h:118 */
+                col = add(col, LambertShade(&r, world, max_depth, &state[pixel_index], frameIndex));
+            }
+            col = div_assign_s(col, (float)ns);
+            col.e[0] = sqrtf(col.e[0]);
+            col.e[1] = sqrtf(col.e[1]);
+            col.e[2] = sqrtf(col.e[2]);
+            o_vec3 c = clip(col);
+            colorBuffer[3 * (size_t)pixel_index + 0] = c.e[0];
+            colorBuffer[3 * (size_t)pixel_index + 1] = c.e[1];
+            colorBuffer[3 * (size_t)pixel_index + 2] = c.e[2];
+        }
+}
+
+void o_render(float *colorBuffer, const o_world *world, const o_camera *camera,
+              o_curand_state *state, int nx, int ny, int samples, int max_depth, int frameIndex) {
+    o_render_window(colorBuffer, world, camera, state, nx, ny, samples, max_depth, frameIndex, 0, ny, 0, nx);
+}
+
+void o_to_rgba8(const float *colorBuffer, int nx, int ny, unsigned char *rgba) { /* render.h:135-146 */
+    for (int i = 0; i < ny; i++)
+        for (int j = 0; j < nx; j++) {
+            size_t pixel_index = (size_t)(ny - 1 - i) * nx + j;
+            for (int c = 0; c < 3; c++) {
+                /* char(255.99 * c): double multiply, truncation toward zero, low 8 bits kept.
+                 * NaN (the reference's cvttsd2si yields INT_MIN, low byte 0) maps to 0. */
+                double d = 255.99 * colorBuffer[3 * pixel_index + c];
+                int iv = (d != d) ? 0 : (int)d;
+                rgba[4 * ((size_t)i * nx + j) + c] = (unsigned char)iv;
+            }
+            rgba[4 * ((size_t)i * nx + j) + 3] = 255;
+        }
+}
+
+/* ------------------------------------------------------------------ createScene.h */
+
+o_world *o_world_from_mesh(const float *points, int n_points, const float *idx3f, int n_tris,
+                           const float *normals, int index_base, const float albedo[3]) { /* createScene.h:175-190 */
+    o_world *w = (o_world *)calloc(1, sizeof(o_world));
+    /* HitableList(int n) -> Hitable() -> new Transform(): position/rotation uninitialised in
+     * the reference (transform.h:8); defined here as the identity. */
+    w->transform.position = v1(0);
+    w->transform.rotation = v1(0);
+    w->transform.scale = v1(1);
+    w->list_size = n_tris;
+    w->list = (o_triangle *)calloc(n_tris > 0 ? n_tris : 1, sizeof(o_triangle));
+    w->albedo = v3(albedo[0], albedo[1], albedo[2]);
+    for (int i = 0; i < n_tris; i++) {
+        int id[3];
+        for (int k = 0; k < 3; k++) {
+            id[k] = (int)idx3f[3 * i + k] - index_base;
+            if (id[k] < 0 || id[k] >= n_points) { o_world_free(w); return NULL; }
+        }
+        o_triangle *tri = &w->list[i];
+        /* reversed winding: {points[idx[2]], points[idx[1]], points[idx[0]]}, createScene.h:183 */
+        for (int k = 0; k < 3; k++) {
+            int p = id[2 - k];
+            tri->vertices[k] = v3(points[3 * p], points[3 * p + 1], points[3 * p + 2]);
+        }
+        tri->transform.position = v1(0); /* new Transform(vec3(0), vec3(0), vec3(1)), createScene.h:184 */
+        tri->transform.rotation = v1(0);
+        tri->transform.scale = v1(1);
+        tri->EPSILON = 0.000001; /* triangle.h:9,22 */
+        tri->backCulling = 0;
+        if (normals) {
+            tri->normal = v3(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]); /* triangle.h:21-29 */
+        } else {
+            o_vec3 edge1 = sub(tri->vertices[1], tri->vertices[0]);              /* triangle.h:14-17 */
+            o_vec3 edge2 = sub(tri->vertices[2], tri->vertices[0]);
+            tri->normal = unit_vector(cross(edge1, edge2));
+        }
+    }
+    return w;
+}
+
+void o_world_free(o_world *w) {
+    if (!w) return;
+    free(w->list);
+    free(w);
+}
+
+/* ------------------------------------------------------------------ Loader/obj_loader.h */
+
+int o_parse_obj(const char *path, float *points, float *idx3f, int *n_points, int *n_tris) { /* obj_loader.h:20-111,120-133 */
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int np = 0, nt = 0;
+    char line[1024];
+    while (fgets(line, sizeof line, f)) {
+        char label[16];
+        int consumed = 0;
+        if (sscanf(line, "%15s%n", label, &consumed) != 1) continue;
+        if (strcmp(label, "v") == 0) {
+            float p[3] = {0, 0, 0};
+            sscanf(line + consumed, "%f %f %f", &p[0], &p[1], &p[2]);
+            if (points) { points[3 * np] = p[0]; points[3 * np + 1] = p[1]; points[3 * np + 2] = p[2]; }
+            np++;
+        } else if (strcmp(label, "f") == 0) {
+            float p[3] = {0, 0, 0};
+            sscanf(line + consumed, "%f %f %f", &p[0], &p[1], &p[2]); /* indices read as floats, 1-based, kept */
+            if (idx3f) { idx3f[3 * nt] = p[0]; idx3f[3 * nt + 1] = p[1]; idx3f[3 * nt + 2] = p[2]; }
+            nt++;
+        }
+    }
+    fclose(f);
+    *n_points = np;
+    *n_tris = nt;
+    if (points) {
+        o_vec3 mean = v3(0, 0, 0);                                        /* computeMean, obj_loader.h:120-126 */
+        for (int i = 0; i < np; i++) mean = add(mean, v3(points[3 * i], points[3 * i + 1], points[3 * i + 2]));
+        mean = divs(mean, (float)np);
+        for (int i = 0; i < np; i++) {                                    /* centering, obj_loader.h:129-133 */
+            points[3 * i] -= mean.e[0];
+            points[3 * i + 1] -= mean.e[1];
+            points[3 * i + 2] -= mean.e[2];
+        }
+    }
+    return 0;
+}

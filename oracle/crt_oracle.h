@@ -1,0 +1,118 @@
+/*
+ * crt_oracle.h — CPU oracle for the list-render hot path of chocorone/CudaRaytracer.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and only as the
+ * checker / the timed CPU baseline.  The product path (cudaraytracer_amd/csrc) never
+ * links, includes or calls it.
+ *
+ * PARITY UNPINNED.  The reference ships no tests, golden images or known-answer vectors
+ * (SURVEY.md §4), it is CUDA (needs nvcc, cuda_runtime.h, curand_kernel.h — all absent
+ * from this image) and therefore cannot be built here without writing stand-ins for
+ * those headers/libraries, which the build rules forbid.  This file is a plain-C,
+ * line-by-line restatement of the reference's algorithm (each function cites the
+ * reference file:line it follows, paths relative to /root/reference/CudaTest/src) and
+ * of cuRAND's published XORWOW algorithm (CUDA Toolkit 12.2 curand_kernel.h, not in the
+ * reference tree).  It defines "the reference on the host CPU" for this repository.
+ *
+ * Floating point: every operation is IEEE-754 binary32 evaluated in source order with
+ * no contraction (build with -ffp-contract=off), except the reference's double-typed
+ * sites, which are kept literally.
+ */
+#ifndef CRT_ORACLE_H
+#define CRT_ORACLE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* core/vec3.h:7-50 */
+typedef struct { float e[3]; } o_vec3;
+
+/* cuRAND XORWOW state (curand_kernel.h `curandStateXORWOW`): only d and v[5] matter on
+ * this path (the Box-Muller fields are never touched). */
+typedef struct { unsigned int d; unsigned int v[5]; } o_curand_state;
+
+/* core/camera.h:16-53 */
+typedef struct {
+    o_vec3 lower_left_corner, horizontal, vertical, origin, x, y, z;
+    float lens_radius;
+} o_camera;
+
+/* hitable/transform.h:6-36 */
+typedef struct { o_vec3 position, rotation, scale; } o_transform;
+
+/* shapes/triangle.h:5-54 (+ the per-object Transform of hitable/hitable.h:52) */
+typedef struct {
+    o_transform transform;
+    float EPSILON;
+    o_vec3 vertices[3];
+    o_vec3 normal;
+    int backCulling;
+} o_triangle;
+
+/* hitable/hitable_list.h:6-73 with a single shared Lambertian(ConstantTexture(albedo))
+ * (createScene.h:180) */
+typedef struct {
+    o_transform transform;
+    o_triangle *list;
+    int list_size;
+    o_vec3 albedo;
+} o_world;
+
+/* ---- RNG: curand_init / curand / curand_uniform (core/deviceManage.h:127, render.h:116) */
+void o_curand_init(unsigned long long seed, unsigned long long subsequence,
+                   unsigned long long offset, o_curand_state *state);
+unsigned int o_curand(o_curand_state *state);
+float o_curand_uniform(o_curand_state *state);
+/* core/deviceManage.h:120-136: state[pi] = curand_init(seed, pi, 0) for pi in [0,nx*ny) */
+void o_set_curand_state(o_curand_state *state, int nx, int ny, unsigned long long seed);
+/* same, for an arbitrary pixel range [first, first+count) written to state[0..count) */
+void o_set_curand_state_range(o_curand_state *state, long long first, long long count,
+                              unsigned long long seed);
+
+/* ---- camera: core/camera.h:18-38, createScene.h:142-154 */
+void o_camera_init(o_camera *cam, const float lookfrom[3], const float lookat[3],
+                   const float vup[3], float vfov, float aspect, float aperture,
+                   float focus_dist);
+
+/* ---- scene pack: createScene.h:175-190 (add_mesh_withNormal).
+ * idx3f are the reference's float-triplet indices; index_base is subtracted after the
+ * int() conversion (0 for the FBX path, 1 for OBJ indices stored undecremented,
+ * Loader/obj_loader.h:62-64).  normals == NULL selects the 5-argument Triangle ctor rule
+ * (shapes/triangle.h:8-19). Returns NULL on bad indices. */
+o_world *o_world_from_mesh(const float *points, int n_points, const float *idx3f,
+                           int n_tris, const float *normals, int index_base,
+                           const float albedo[3]);
+void o_world_free(o_world *w);
+
+/* ---- OBJ: Loader/obj_loader.h:20-133. Two-call protocol: pass NULL buffers to count. */
+int o_parse_obj(const char *path, float *points, float *idx3f, int *n_points, int *n_tris);
+
+/* ---- the render kernel, run serially pixel by pixel in index order
+ * (core/render.h:105-129).  colorBuffer: nx*ny*3 floats, row 0 = image bottom.
+ * state: nx*ny entries.  rows [row_begin,row_end) and columns [col_begin,col_end) are
+ * rendered (the full image is row 0..ny, col 0..nx); untouched pixels are left alone. */
+void o_render_window(float *colorBuffer, const o_world *world, const o_camera *camera,
+                     o_curand_state *state, int nx, int ny, int samples, int max_depth,
+                     int frameIndex, int row_begin, int row_end, int col_begin,
+                     int col_end);
+void o_render(float *colorBuffer, const o_world *world, const o_camera *camera,
+              o_curand_state *state, int nx, int ny, int samples, int max_depth,
+              int frameIndex);
+
+/* Diagnostics for tests: closest hit of ONE ray through the world list
+ * (core/render.h:75 -> hitable.h:29-38 -> hitable_list.h:76-91). Returns hit flag. */
+int o_world_hit(const o_world *world, const float origin[3], const float direction[3],
+                float *t_out, int *index_out, float normal_out[3]);
+
+/* ---- WritePng's pixel conversion (core/render.h:135-146): RGBA8, vertical flip,
+ * char(255.99*c). rgba: nx*ny*4 bytes. */
+void o_to_rgba8(const float *colorBuffer, int nx, int ny, unsigned char *rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,167 @@
+"""ctypes binding of the CPU oracle (oracle/libcrt_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product package.  PARITY UNPINNED (see crt_oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcrt_oracle.so")
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc, -ffp-contract=off)."""
+    src = [os.path.join(_HERE, f) for f in ("crt_oracle.c", "crt_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libcrt_oracle.so"])
+    return _LIB_PATH
+
+
+class CurandState(C.Structure):
+    _fields_ = [("d", C.c_uint), ("v", C.c_uint * 5)]
+
+
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_float * 3) for n in
+                ("lower_left_corner", "horizontal", "vertical", "origin", "x", "y", "z")] + \
+               [("lens_radius", C.c_float)]
+
+
+STATE_DTYPE = np.dtype([("d", np.uint32), ("v", np.uint32, (5,))])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.o_curand_init.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.POINTER(CurandState)]
+        L.o_curand.argtypes = [C.POINTER(CurandState)]
+        L.o_curand.restype = C.c_uint
+        L.o_curand_uniform.argtypes = [C.POINTER(CurandState)]
+        L.o_curand_uniform.restype = C.c_float
+        L.o_set_curand_state_range.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_ulonglong]
+        L.o_camera_init.argtypes = [C.POINTER(Camera), fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.o_world_from_mesh.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp]
+        L.o_world_from_mesh.restype = C.c_void_p
+        L.o_world_free.argtypes = [C.c_void_p]
+        L.o_parse_obj.argtypes = [C.c_char_p, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.o_render_window.argtypes = [fp, C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_int] * 9
+        L.o_world_hit.argtypes = [C.c_void_p, fp, fp, fp, C.POINTER(C.c_int), fp]
+        L.o_world_hit.restype = C.c_int
+        L.o_to_rgba8.argtypes = [fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def curand_stream(seed, subsequence, offset, n):
+    """First n curand() u32 outputs and curand_uniform floats of (seed, subsequence, offset)."""
+    L = lib()
+    s = CurandState()
+    L.o_curand_init(seed, subsequence, offset, C.byref(s))
+    s2 = CurandState.from_buffer_copy(s)
+    u32 = np.array([L.o_curand(C.byref(s)) for _ in range(n)], dtype=np.uint32)
+    f32 = np.array([L.o_curand_uniform(C.byref(s2)) for _ in range(n)], dtype=np.float32)
+    return u32, f32
+
+
+def curand_states(first, count, seed=0):
+    st = np.zeros(count, dtype=STATE_DTYPE)
+    lib().o_set_curand_state_range(st.ctypes.data, first, count, seed)
+    return st
+
+
+def make_camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist):
+    cam = Camera()
+    lib().o_camera_init(C.byref(cam), _f3(lookfrom), _f3(lookat), _f3(vup),
+                        vfov, aspect, aperture, focus_dist)
+    return cam
+
+
+def camera_as_array(cam):
+    return np.array(list(cam.lower_left_corner) + list(cam.horizontal) + list(cam.vertical) +
+                    list(cam.origin) + list(cam.x) + list(cam.y) + list(cam.z) + [cam.lens_radius],
+                    dtype=np.float32)
+
+
+class World:
+    def __init__(self, points, idx3f, normals=None, index_base=0, albedo=(0.65, 0.05, 0.05)):
+        self.points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        self.idx3f = np.ascontiguousarray(idx3f, dtype=np.float32).reshape(-1, 3)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        alb = np.array(albedo, dtype=np.float32)
+        self.handle = lib().o_world_from_mesh(
+            _fp(self.points), len(self.points), _fp(self.idx3f), len(self.idx3f),
+            None if self.normals is None else _fp(self.normals), index_base, _fp(alb))
+        if not self.handle:
+            raise ValueError("o_world_from_mesh: vertex index out of range")
+        self.n_tris = len(self.idx3f)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().o_world_free(self.handle)
+            self.handle = None
+
+    def hit(self, origin, direction):
+        t = C.c_float()
+        idx = C.c_int()
+        nrm = (C.c_float * 3)()
+        flag = lib().o_world_hit(self.handle, _f3(origin), _f3(direction), C.byref(t), C.byref(idx), nrm)
+        return bool(flag), np.float32(t.value), idx.value, np.array(list(nrm), dtype=np.float32)
+
+
+def parse_obj(path):
+    L = lib()
+    npnt, ntri = C.c_int(), C.c_int()
+    if L.o_parse_obj(path.encode(), None, None, C.byref(npnt), C.byref(ntri)) != 0:
+        raise FileNotFoundError(path)
+    pts = np.zeros((npnt.value, 3), dtype=np.float32)
+    idx = np.zeros((ntri.value, 3), dtype=np.float32)
+    L.o_parse_obj(path.encode(), _fp(pts), _fp(idx), C.byref(npnt), C.byref(ntri))
+    return pts, idx
+
+
+def render(world, cam, nx, ny, samples, seed=0, window=None, states=None, max_depth=8, frame=0):
+    """Serial reference render. window=(row_begin,row_end,col_begin,col_end) renders a crop;
+    RNG states are created for exactly the pixels needed (stream = global pixel index).
+    Returns (colorBuffer[ny,nx,3] float32 with zeros outside the window, states)."""
+    L = lib()
+    if window is None:
+        window = (0, ny, 0, nx)
+    r0, r1, c0, c1 = window
+    buf = np.zeros((ny, nx, 3), dtype=np.float32)
+    if states is None:
+        states = np.zeros(nx * ny, dtype=STATE_DTYPE)
+        # stream 0 is always needed (get_ray draws from &state[0], core/render.h:118)
+        L.o_set_curand_state_range(states.ctypes.data, 0, 1, seed)
+        for y in range(r0, r1):
+            first = y * nx + c0
+            L.o_set_curand_state_range(states[first:].ctypes.data, first, c1 - c0, seed)
+    L.o_render_window(_fp(buf), world.handle, C.byref(cam), states.ctypes.data,
+                      nx, ny, samples, max_depth, frame, r0, r1, c0, c1)
+    return buf, states
+
+
+def to_rgba8(buf):
+    ny, nx, _ = buf.shape
+    out = np.zeros((ny, nx, 4), dtype=np.uint8)
+    b = np.ascontiguousarray(buf, dtype=np.float32)
+    lib().o_to_rgba8(_fp(b), nx, ny, out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return out

@@ -1,0 +1,126 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/crt.h declares,
+its host-only entry points (camera, OBJ parse, RGBA8/PNG) agree with the oracle, and its
+compute entry points fail loudly — not silently fall back — without a HIP device."""
+import ctypes as C
+import os
+import re
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from cudaraytracer_amd import _lib, api, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "crt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(crt_built):
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(crt_built, n), "libcrt_hip.so does not export %s" % n
+        assert n in _lib.PROTOTYPES, "no ctypes prototype for %s" % n
+    assert set(_lib.PROTOTYPES) == set(names)
+    assert crt_built.crt_abi_version() == 1
+
+
+def test_camera_matches_oracle(crt_built, oracle):
+    cams = [((0, 100, 1000), (0, 150, 0), 40.0, 1920, 1080),
+            ((278, 273, -800), (278, 273, 0), 40.0, 800, 600),
+            ((0, 0, 0), (0, 0, -1), 40.0, 256, 256),
+            ((3.5, -2.25, 7.0), (0.1, 0.2, 0.3), 63.7, 317, 211)]
+    for lf, la, vfov, nx, ny in cams:
+        a = api.create_camera(nx, ny, lf, la, 10.0, 0.0, vfov).as_array()
+        o = oracle.camera_as_array(oracle.make_camera(lf, la, (0, 1, 0), vfov,
+                                                      np.float32(nx) / np.float32(ny), 0.0, 10.0))
+        assert np.array_equal(a.view(np.uint32), o.view(np.uint32))
+    c = api.init_camera(1024, 512)      # the reference's live call site
+    assert list(c.c.origin) == [0.0, 100.0, 1000.0] and c.c.lens_radius == 0.0
+
+
+def test_parse_obj_matches_oracle(crt_built, oracle, tmp_path):
+    sc = scenes.displaced_sphere(5, 7, index_base=1)
+    path = scenes.write_obj(str(tmp_path / "m.obj"), sc)
+    p1, i1 = api.parse_obj(path)
+    p2, i2 = oracle.parse_obj(path)
+    assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32)) and np.array_equal(i1, i2)
+    # `a//n` and `a/b/c` faces: the leading index of each token is what gets read
+    with open(str(tmp_path / "n.obj"), "w") as f:
+        f.write("vn 0 1 0\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1//1 2//1 3//1\nf 1/1/1 3/2/1 2/3/1\n")
+    p, i = api.parse_obj(str(tmp_path / "n.obj"))
+    assert i.tolist() == [[1, 2, 3], [1, 3, 2]] and p.shape == (3, 3)
+    with pytest.raises(_lib.CrtError):
+        api.parse_obj(str(tmp_path / "missing.obj"))
+
+
+def decode_png(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xFFFFFFFF
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    nx, ny, depth, ctype = hdr[:4]
+    assert depth == 8 and ctype == 6
+    raw = zlib.decompress(idat)
+    rows = np.frombuffer(raw, dtype=np.uint8).reshape(ny, nx * 4 + 1)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(ny, nx, 4)
+
+
+def test_rgba8_and_png_match_oracle(crt_built, oracle, golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "c2_cornell_100x75x16.npz"))
+    rgb = g["rgb"].copy()
+    rgb[3, 4, 1] = np.nan
+    assert np.array_equal(api.to_rgba8(rgb), oracle.to_rgba8(rgb))
+    path = api.WritePng(100, 75, 7, rgb, folder=str(tmp_path / "images" / "moveTest"))
+    assert path.endswith("picture_7.png")
+    assert np.array_equal(decode_png(path), oracle.to_rgba8(rgb))
+
+
+def test_compute_entry_points_fail_loudly_without_device(crt_built):
+    if crt_built.crt_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    L = crt_built
+    assert not L.crt_rng_create(0, 16, 0)
+    assert b"no HIP device" in L.crt_last_error()
+    sc = scenes.quad()
+    with pytest.raises(_lib.CrtError) as e:
+        api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"])
+    assert "no HIP device" in str(e.value)
+    out = np.zeros(12, dtype=np.float32)
+    cam = api.init_camera(2, 2)
+    rc = L.crt_render(2, 2, 1, 8, 0, None, C.byref(cam.c), 0, out.ctypes.data_as(C.POINTER(C.c_float)))
+    assert rc == _lib.CRT_ERR_NO_DEVICE
+    with pytest.raises(_lib.CrtError):
+        api.renderListAnimation(2, 2, 1, 8, 0, 0, None, cam, None)
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_handle", None)
+    monkeypatch.setattr(_lib, "_LIB", str(tmp_path / "libcrt_hip.so"))
+    with pytest.raises(_lib.CrtError) as e:
+        _lib.lib()
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "cudaraytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "pyoracle" not in text and "crt_oracle" not in text and "libcrt_oracle" not in text, fn

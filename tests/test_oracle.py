@@ -1,0 +1,258 @@
+"""CPU tests of the oracle (oracle/crt_oracle.c) — the checker itself.
+
+PARITY UNPINNED: the reference holds no tests or golden vectors and cannot
+be built here, so the oracle is pinned against (a) an independent pure-Python restatement
+of cuRAND's XORWOW incl. the 2^67 subsequence skip, (b) hand-derived closed-form cases of
+the reference's closest-hit rules, (c) its own committed outputs (regression).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cudaraytracer_amd import scenes
+
+MASK32 = 0xFFFFFFFF
+
+
+# ----------------------------------------------------------------- independent XORWOW
+def py_seed_state(seed):
+    s0 = (seed & MASK32) ^ 0xaad26b49
+    s1 = ((seed >> 32) & MASK32) ^ 0xf7dcefdd
+    t0 = (1099087573 * s0) & MASK32
+    t1 = (2591861531 * s1) & MASK32
+    d = (6615241 + t1 + t0) & MASK32
+    v = [(123456789 + t0) & MASK32, 362436069 ^ t0, (521288629 + t1) & MASK32, 88675123 ^ t1,
+         (5783321 + t0) & MASK32]
+    return d, v
+
+
+def py_step(v):
+    t = v[0] ^ (v[0] >> 2)
+    v4 = (v[4] ^ ((v[4] << 4) & MASK32)) ^ (t ^ ((t << 1) & MASK32))
+    return [v[1], v[2], v[3], v[4], v4]
+
+
+def pack(v):
+    return sum(w << (32 * i) for i, w in enumerate(v))
+
+
+def unpack(x):
+    return [(x >> (32 * i)) & MASK32 for i in range(5)]
+
+
+def py_matrix():
+    return [pack(py_step(unpack(1 << b))) for b in range(160)]
+
+
+def py_apply(x, m):
+    r = 0
+    b = 0
+    while x:
+        if x & 1:
+            r ^= m[b]
+        x >>= 1
+        b += 1
+    return r
+
+
+def py_square(m):
+    return [py_apply(row, m) for row in m]
+
+
+@pytest.fixture(scope="module")
+def jump67():
+    m = py_matrix()
+    for _ in range(67):
+        m = py_square(m)
+    return m
+
+
+def py_skip_subsequence(v, sub, jump67):
+    x = pack(v)
+    m = jump67
+    while sub:
+        if sub & 1:
+            x = py_apply(x, m)
+        sub >>= 1
+        if sub:
+            m = py_square(m)
+    return unpack(x)
+
+
+def py_outputs(d, v, n):
+    out = []
+    for _ in range(n):
+        v = py_step(v)
+        d = (d + 362437) & MASK32
+        out.append((v[4] + d) & MASK32)
+    return out
+
+
+def test_xorwow_recurrence_matches_python(oracle):
+    for seed in (0, 1, 0x123456789ABCDEF):
+        d, v = py_seed_state(seed)
+        u32, f32 = oracle.curand_stream(seed, 0, 0, 16)
+        assert list(u32) == py_outputs(d, v, 16)
+
+
+def test_xorwow_offset_equals_stepping(oracle):
+    for off in (1, 5, 1000, 123457):
+        d, v = py_seed_state(0)
+        for _ in range(off):
+            v = py_step(v)
+        d = (d + 362437 * off) & MASK32
+        u32, _ = oracle.curand_stream(0, 0, off, 4)
+        assert list(u32) == py_outputs(d, v, 4)
+
+
+@pytest.mark.parametrize("sub", [1, 2, 3, 4, 5, 63, 64, 65535, 2073599, 8294399])
+def test_xorwow_subsequence_skip_matches_python(oracle, jump67, sub):
+    d, v = py_seed_state(0)
+    v = py_skip_subsequence(v, sub, jump67)
+    u32, _ = oracle.curand_stream(0, sub, 0, 8)
+    assert list(u32) == py_outputs(d, v, 8)
+
+
+def test_xorwow_uniform_mapping(oracle):
+    u32, f32 = oracle.curand_stream(0, 0, 0, 64)
+    k = np.float32(2.3283064e-10)
+    expect = u32.astype(np.float32) * k + (k / np.float32(2.0))
+    assert np.array_equal(expect.astype(np.float32), f32)
+    assert (f32 > 0).all() and (f32 <= 1).all()
+
+
+def test_xorwow_kat_regression(oracle, golden_dir):
+    kat = np.load(os.path.join(golden_dir, "xorwow_kat.npz"))
+    for key in kat.files:
+        if key.startswith("u32_"):
+            _, seed, sub, off = key.split("_")
+            u32, f32 = oracle.curand_stream(int(seed), int(sub), int(off), 8)
+            assert np.array_equal(u32, kat[key]), key
+            assert np.array_equal(f32, kat["f32" + key[3:]]), key
+    st = oracle.curand_states(0, 300, 0)
+    assert np.array_equal(np.concatenate([st["d"][:, None], st["v"]], axis=1), kat["states_0_300"])
+
+
+# ----------------------------------------------------------------- closest-hit rules
+def _world(oracle, tris, normals=None):
+    pts = np.array(tris, dtype=np.float32).reshape(-1, 3)
+    n = len(pts) // 3
+    # the scene pack reverses the winding (createScene.h:183): give indices reversed so the
+    # stored vertex order is the one written in the test
+    idx = np.array([[3 * i + 2, 3 * i + 1, 3 * i] for i in range(n)], dtype=np.float32)
+    return oracle.World(pts, idx, normals)
+
+
+def test_hit_front_and_cull(oracle):
+    tri = [(-1, -1, -5), (1, -1, -5), (0, 1, -5)]
+    w = _world(oracle, [tri], normals=[(0, 0, -1)])
+    flag, t, idx, n = w.hit((0, 0, 0), (0, 0, -1))
+    assert flag and idx == 0 and t == np.float32(5.0)
+    # stored normal facing the ray origin: dot(d, n) < 0 -> culled (shapes/triangle.h:61)
+    w2 = _world(oracle, [tri], normals=[(0, 0, 1)])
+    assert not w2.hit((0, 0, 0), (0, 0, -1))[0]
+
+
+def test_hit_behind_camera_wins(oracle):
+    """No t-range test in Triangle::collision_detection: the smallest t wins, negative too."""
+    front = [(-1, -1, -5), (1, -1, -5), (0, 1, -5)]
+    behind = [(-1, -1, 3), (1, -1, 3), (0, 1, 3)]
+    w = _world(oracle, [front, behind], normals=[(0, 0, -1), (0, 0, -1)])
+    flag, t, idx, _ = w.hit((0, 0, 0), (0, 0, -1))
+    assert flag and idx == 1 and t == np.float32(-3.0)
+
+
+def test_hit_tie_lowest_index(oracle):
+    tri = [(-1, -1, -5), (1, -1, -5), (0, 1, -5)]
+    w = _world(oracle, [tri, tri, tri], normals=[(0, 0, -1)] * 3)
+    flag, t, idx, _ = w.hit((0, 0, 0), (0.01, 0.02, -1))
+    assert flag and idx == 0
+
+
+def test_parallel_and_degenerate_miss(oracle):
+    tri = [(-1, 0, -5), (1, 0, -5), (0, 0, -7)]                     # lies in the plane y = 0
+    w = _world(oracle, [tri], normals=[(0, 0, 0)])                  # normal 0 passes the cull (dot == 0)
+    assert not w.hit((0, 0, 0), (0, 0, -1))[0]                      # |a| < EPSILON
+    deg = [(-1, -1, -5), (1, 1, -5), (1, 1, -5)]
+    w2 = _world(oracle, [deg])                                      # 5-arg ctor: NaN normal
+    assert not w2.hit((0, 0, 0), (0, 0, -1))[0]
+
+
+def test_direction_is_normalised_twice_but_t_is_metric(oracle):
+    tri = [(-10, -10, -5), (10, -10, -5), (0, 10, -5)]
+    w = _world(oracle, [tri], normals=[(0, 0, -1)])
+    _, t1, _, _ = w.hit((0, 0, 0), (0, 0, -1))
+    _, t2, _, _ = w.hit((0, 0, 0), (0, 0, -10))                     # un-normalised camera ray (focus 10)
+    assert t1 == t2 == np.float32(5.0)
+
+
+# ----------------------------------------------------------------- render regression
+RENDERS = ["c1_quad_256x256x1", "c2_cornell_100x75x16", "sphere1000_96x54x4", "soup96_48x48x4"]
+FACTORY = {
+    "c1_quad_256x256x1": scenes.quad,
+    "c2_cornell_100x75x16": scenes.cornell32,
+    "sphere1000_96x54x4": lambda: scenes.displaced_sphere(20, 25),
+    "soup96_48x48x4": lambda: scenes.random_soup(96, 7),
+}
+
+
+def oracle_scene(oracle, sc, nx, ny):
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    c = sc["camera"]
+    cam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"],
+                             np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
+    return w, cam
+
+
+@pytest.mark.parametrize("name", RENDERS)
+def test_render_matches_golden(oracle, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    nx, ny, spp = int(g["nx"]), int(g["ny"]), int(g["spp"])
+    w, cam = oracle_scene(oracle, FACTORY[name](), nx, ny)
+    assert np.array_equal(oracle.camera_as_array(cam), g["camera"])
+    buf, states = oracle.render(w, cam, nx, ny, spp)
+    assert np.array_equal(buf.view(np.uint32), g["rgb"].view(np.uint32))
+    assert np.array_equal(oracle.to_rgba8(buf), g["rgba"])
+    after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+    assert np.array_equal(after[:2048], g["states_after"])
+    org = g["camera"][9:12]
+    for d, (flag, t, idx) in zip(g["rays"], g["hits"]):
+        f2, t2, i2, _ = w.hit(org, d)
+        assert f2 == bool(flag) and i2 == int(idx)
+        if f2:
+            assert np.float32(t) == t2
+
+
+def test_window_equals_full(oracle):
+    sc = scenes.random_soup(48, 3)
+    nx, ny, spp = 40, 32, 3
+    w, cam = oracle_scene(oracle, sc, nx, ny)
+    full, _ = oracle.render(w, cam, nx, ny, spp)
+    win = (8, 20, 5, 33)
+    crop, _ = oracle.render(w, cam, nx, ny, spp, window=win)
+    r0, r1, c0, c1 = win
+    assert np.array_equal(crop[r0:r1, c0:c1].view(np.uint32), full[r0:r1, c0:c1].view(np.uint32))
+    assert not crop[:r0].any() and not crop[r1:].any()
+
+
+def test_rgba8_conversion(oracle):
+    buf = np.zeros((2, 3, 3), dtype=np.float32)
+    buf[0, 0] = (0.0, 0.5, 1.0)          # bottom-left pixel
+    buf[1, 2] = (0.25, np.nan, 0.999)    # top-right pixel
+    out = oracle.to_rgba8(buf)
+    assert out.shape == (2, 3, 4)
+    assert list(out[1, 0]) == [0, 127, 255, 255]           # flipped: bottom row is last
+    assert list(out[0, 2]) == [int(255.99 * 0.25), 0, int(255.99 * np.float32(0.999)), 255]
+
+
+def test_obj_parse_and_centering(oracle, tmp_path):
+    sc = scenes.displaced_sphere(3, 4, index_base=1)
+    path = scenes.write_obj(str(tmp_path / "s.obj"), sc)
+    pts, idx = oracle.parse_obj(path)
+    assert pts.shape == sc["points"].shape and np.array_equal(idx, sc["idx"])
+    mean = np.zeros(3, dtype=np.float32)
+    for p in sc["points"]:
+        mean = (mean + p).astype(np.float32)
+    mean = (mean / np.float32(len(sc["points"]))).astype(np.float32)
+    assert np.array_equal(pts, (sc["points"] - mean).astype(np.float32))

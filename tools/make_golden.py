@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the CPU oracle (oracle/crt_oracle.c).
+
+PARITY UNPINNED: the reference ships no golden vectors and cannot be built in this image
+(CUDA + cuRAND + FBX SDK), so these files pin the ORACLE (regression) and carry its outputs
+to the GPU box; they are not outputs of the reference program.  Re-run after any
+intentional oracle change:   python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cudaraytracer_amd import scenes  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# (name, scene factory, nx, ny, spp)
+RENDERS = [
+    ("c1_quad_256x256x1", scenes.quad, 256, 256, 1),                       # BASELINE configs[0], full
+    ("c2_cornell_100x75x16", scenes.cornell32, 100, 75, 16),               # configs[1] at 1/8 size
+    ("sphere1000_96x54x4", lambda: scenes.displaced_sphere(20, 25), 96, 54, 4),
+    ("soup96_48x48x4", lambda: scenes.random_soup(96, 7), 48, 48, 4),
+]
+
+KAT_SUBSEQ = [0, 1, 2, 3, 4, 5, 63, 64, 65535, 2073599, 8294399, (1 << 31) - 1]
+
+
+def camera_of(sc, nx, ny):
+    c = sc["camera"]
+    return po.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"],
+                          np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # 1. XORWOW known answers (seed 0 and one 64-bit seed, offset 0 and 5)
+    kat = {}
+    for seed in (0, 0x123456789ABCDEF):
+        for sub in KAT_SUBSEQ:
+            for off in (0, 5):
+                u32, f32 = po.curand_stream(seed, sub, off, 8)
+                kat["u32_%d_%d_%d" % (seed, sub, off)] = u32
+                kat["f32_%d_%d_%d" % (seed, sub, off)] = f32
+    st = po.curand_states(0, 300, 0)
+    kat["states_0_300"] = np.concatenate([st["d"][:, None], st["v"]], axis=1)
+    np.savez_compressed(os.path.join(OUT, "xorwow_kat.npz"), **kat)
+
+    # 2. framebuffers + per-ray closest hits
+    for name, factory, nx, ny, spp in RENDERS:
+        sc = factory()
+        w = po.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        cam = camera_of(sc, nx, ny)
+        buf, states = po.render(w, cam, nx, ny, spp)
+        # closest hit of the pixel-centre rays of a coarse grid (pins tie-breaking, negative t)
+        org = np.array(list(cam.origin), dtype=np.float32)
+        llc = np.array(list(cam.lower_left_corner), dtype=np.float32)
+        hor = np.array(list(cam.horizontal), dtype=np.float32)
+        ver = np.array(list(cam.vertical), dtype=np.float32)
+        rays, hits = [], []
+        for gy in range(0, ny, max(1, ny // 12)):
+            for gx in range(0, nx, max(1, nx // 12)):
+                u = np.float32(gx + 0.5) / np.float32(nx)
+                v = np.float32(gy + 0.5) / np.float32(ny)
+                d = ((llc + u * hor) + v * ver) - org
+                flag, t, idx, nrm = w.hit(org, d)
+                rays.append(d)
+                hits.append((float(flag), float(t) if flag else 0.0, float(idx)))
+        after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), rgb=buf, camera=po.camera_as_array(cam),
+                            rays=np.array(rays, dtype=np.float32), hits=np.array(hits, dtype=np.float64),
+                            rgba=po.to_rgba8(buf), states_after=after[:2048],
+                            states_after_colsum=after.astype(np.uint64).sum(axis=0),
+                            nx=nx, ny=ny, spp=spp)
+        print(name, buf.shape, "hit-rays %d/%d" % (int(sum(h[0] for h in hits)), len(hits)))
+
+
+if __name__ == "__main__":
+    main()
