@@ -152,6 +152,9 @@ struct crt_scene {
     float* d_base = nullptr;      // n x 12: v0 v1 v2 n
     float* d_shade_n = nullptr;   // n x 3: normal after the two rotate() calls of Hitable::hit
     float* d_rec = nullptr;       // n x 16 derived records (prepass output)
+    float4* d_cls = nullptr;      // 4 planes x n_pad classification records (tiled variant)
+    int n_pad = 0;
+    bool tiled_safe = false;      // all coordinates finite and |c| <= 2^38
 };
 
 struct crt_rng {
@@ -213,6 +216,8 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
         fail(CRT_ERR_NO_DEVICE, "crt_scene_from_mesh: no HIP device");
         return nullptr;
     }
+    float max_abs = 0.0f;
+    bool finite = true;
     std::vector<float> base((size_t)std::max(n_tris, 1) * crt::kBaseFloats);
     std::vector<float> shade((size_t)std::max(n_tris, 1) * 3);
     for (int i = 0; i < n_tris; ++i) {
@@ -237,6 +242,10 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
             n = hunit(hcross(e1, e2));
         }
         b[9] = n.x; b[10] = n.y; b[11] = n.z;
+        for (int k = 0; k < 9; ++k) {
+            finite = finite && std::isfinite(b[k]);
+            max_abs = std::max(max_abs, fabsf(b[k]));
+        }
         // rec.normal = rotate(rec.normal, transform->rotation) at the triangle and again
         // at the world list (hitable/hitable.h:36), both with rotation 0.
         H3 sn = hrotate(hrotate(n, H3{0, 0, 0}), H3{0, 0, 0});
@@ -245,12 +254,15 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
     crt_scene* s = new (std::nothrow) crt_scene;
     if (!s) { fail(CRT_ERR_NOMEM, "crt_scene_from_mesh: out of memory"); return nullptr; }
     s->n_tris = n_tris;
+    s->n_pad = (std::max(n_tris, 1) + 63) / 64 * 64;
+    s->tiled_safe = finite && max_abs <= 274877906944.0f;   // 2^38
     memcpy(s->albedo, albedo, sizeof s->albedo);
     hipError_t e = hipGetDevice(&s->device);
     size_t nalloc = (size_t)std::max(n_tris, 1);
     if (e == hipSuccess) e = hipMalloc(&s->d_base, nalloc * crt::kBaseFloats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&s->d_shade_n, nalloc * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&s->d_rec, nalloc * crt::kRecFloats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&s->d_cls, (size_t)crt::kClsPlanes * s->n_pad * sizeof(float4));
     if (e == hipSuccess) e = hipMemcpy(s->d_base, base.data(), nalloc * crt::kBaseFloats * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_shade_n, shade.data(), nalloc * 3 * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -324,6 +336,7 @@ void crt_scene_free(crt_scene* s) {
     if (s->d_base) (void)hipFree(s->d_base);
     if (s->d_shade_n) (void)hipFree(s->d_shade_n);
     if (s->d_rec) (void)hipFree(s->d_rec);
+    if (s->d_cls) (void)hipFree(s->d_cls);
     delete s;
 }
 
@@ -398,6 +411,18 @@ int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* r
 
     HIP_TRY(crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, scene->d_rec, stream));
 
+    // public variant numbering (crt_set_kernel_variant): 0 auto, 1 brute force, 2 tiled,
+    // 3 tiled with tiny list capacities (exercises the overflow fallbacks)
+    bool cam_ok = true;
+    for (int k = 0; k < 3; ++k)
+        cam_ok = cam_ok && std::isfinite(camera->lower_left_corner[k]) && std::isfinite(camera->horizontal[k]) &&
+                 std::isfinite(camera->vertical[k]) && std::isfinite(camera->origin[k]) &&
+                 fabsf(camera->origin[k]) <= 274877906944.0f && fabsf(camera->lower_left_corner[k]) <= 274877906944.0f;
+    const bool tiled_ok = scene->tiled_safe && cam_ok && scene->n_tris > 0;
+    int kernel_variant = 0;
+    if (g_variant == 0 || g_variant == 2) kernel_variant = tiled_ok ? 1 : 0;
+    else if (g_variant == 3) kernel_variant = tiled_ok ? 2 : 0;
+
     crt::RenderParams p;
     memcpy(p.cam.llc, camera->lower_left_corner, 12);
     memcpy(p.cam.horizontal, camera->horizontal, 12);
@@ -414,8 +439,11 @@ int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* r
         HIP_TRY(hipEventCreate(&g_ev_start));
         HIP_TRY(hipEventCreate(&g_ev_stop));
     }
+    if (kernel_variant != 0)
+        HIP_TRY(crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p.cam, scene->d_cls, stream));
     HIP_TRY(hipEventRecord(g_ev_start, stream));
-    HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_shade_n, rng->d_state, d_rgb, g_variant, stream));
+    HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
+                               d_rgb, kernel_variant, stream));
     HIP_TRY(hipEventRecord(g_ev_stop, stream));
     g_ev_valid = true;
     return CRT_OK;

@@ -25,6 +25,17 @@ constexpr int kBaseFloats = 12;
 // ones Triangle::collision_detection recomputes for every ray.
 constexpr int kRecFloats = 16;
 
+// Classification record (tiled variant), 16 floats = 4 float4 planes (SoA, plane-major:
+// cls[plane * n_pad + i]) so that a wavefront with lane = triangle reads 1 KiB per load:
+//   plane 0: (A, B, C, M) of dn  = d.n                 (cull test, triangle.h:61)
+//   plane 1: (A, B, C, M) of a   = d.(e2 x e1)         (triangle.h:71-72)
+//   plane 2: (A, B, C, M) of su  = d.(e2 x s)          (triangle.h:82)
+//   plane 3: (A, B, C, M) of dq  = d.q                 (triangle.h:88)
+// F(u,v) = A + u*B + v*C is the exact value of the form on the un-normalised camera
+// direction d0(u,v) = (llc - o) + u*horizontal + v*vertical; M bounds |G|_1-type magnitudes
+// used for the rounding slack.
+constexpr int kClsPlanes = 4;
+
 // EPSILON of both Triangle ctors the scene pack can reach (shapes/triangle.h:9,22).
 constexpr float kTriEpsilon = 0.000001f;
 
@@ -53,7 +64,13 @@ hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long c
                            uint64_t seed, const uint32_t* d_jump, hipStream_t stream);
 hipError_t launch_tri_prepass(const float* d_base, int n_tris, const float origin[3],
                               float* d_rec, hipStream_t stream);
-hipError_t launch_render(const RenderParams& p, const float* d_rec, const float* d_shade_n,
-                         uint32_t* d_state, float* d_rgb, int variant, hipStream_t stream);
+hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const CameraPOD& cam,
+                              float4* d_cls, hipStream_t stream);
+// variant 0: brute force (every ray x every triangle); 1: tiled (conservative region/tile
+// classification + exact test on survivors); 2: tiled with tiny list capacities (tests the
+// overflow fallbacks).  d_cls may be null for variant 0.
+hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
+                         const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
+                         hipStream_t stream);
 
 }  // namespace crt

@@ -163,6 +163,16 @@ __device__ __forceinline__ V3 unit_vector(V3 v) {
     return V3{v.x / len, v.y / len, v.z / len};
 }
 
+// Camera::get_ray's direction with offset = 0 (core/camera.h:43):
+// ((lower_left_corner + s*horizontal) + t*vertical) - origin, component-wise.
+__device__ __forceinline__ V3 camera_direction(const CameraPOD& c, float u, float v) {
+    V3 d;
+    d.x = ((c.llc[0] + u * c.horizontal[0]) + v * c.vertical[0]) - c.origin[0];
+    d.y = ((c.llc[1] + u * c.horizontal[1]) + v * c.vertical[1]) - c.origin[1];
+    d.z = ((c.llc[2] + u * c.horizontal[2]) + v * c.vertical[2]) - c.origin[2];
+    return d;
+}
+
 // backgroundSky (core/render.h:41-46) given v = unit_vector(d0) already.
 __device__ __forceinline__ V3 sky_from_unit(V3 v) {
     float t = 0.5f * (v.y + 1.0f);
@@ -170,66 +180,62 @@ __device__ __forceinline__ V3 sky_from_unit(V3 v) {
     return V3{1.0f + t * (0.5f - 1.0f), 1.0f + t * (0.7f - 1.0f), 1.0f + t * (1.0f - 1.0f)};
 }
 
-// Closest hit of HitableList::collision_detection (hitable/hitable_list.h:76-91) over the
-// derived records: minimum t over all triangles that pass Triangle::collision_detection
-// (any sign of t, no range test), lowest index on ties, NaN never accepted.
-// `rec` is wave-uniform; d is this lane's twice-normalised direction.
-__device__ __forceinline__ void closest_hit_list(const float* __restrict__ rec, int n_tris,
-                                                 V3 d, float& closest, int& hit_idx) {
-    closest = FLT_MAX;   // double closest_so_far = t_max (FLT_MAX), hitable_list.h:82
-    hit_idx = -1;
-    for (int i = 0; i < n_tris; ++i) {
-        const float* __restrict__ r = rec + (size_t)i * kRecFloats;   // uniform -> scalar loads
-        const float nx = r[0], ny = r[1], nz = r[2];
-        const float e2x = r[3], e2y = r[4], e2z = r[5];
-        const float e1x = r[6], e1y = r[7], e1z = r[8];
-        const float sx = r[9], sy = r[10], sz = r[11];
-        const float qx = r[12], qy = r[13], qz = r[14];
-        const float tq = r[15];
+// Triangle::collision_detection (shapes/triangle.h:57-100) on one derived record for this
+// lane's twice-normalised direction d, followed by the list's accept rule
+// `hit && tmp_rec.t < closest_so_far` (hitable/hitable_list.h:84).  `r` and `i` are
+// wave-uniform: the record arrives through scalar loads and feeds the VALU as SGPR operands;
+// after each of the reference's rejection tests the wavefront votes and leaves as soon as no
+// lane is alive.
+__device__ __forceinline__ void exact_test(const float* __restrict__ r, int i, V3 d,
+                                           float& closest, int& hit_idx) {
+    const float nx = r[0], ny = r[1], nz = r[2];
+    const float e2x = r[3], e2y = r[4], e2z = r[5];
+    const float e1x = r[6], e1y = r[7], e1z = r[8];
+    const float sx = r[9], sy = r[10], sz = r[11];
+    const float qx = r[12], qy = r[13], qz = r[14];
+    const float tq = r[15];
 
-        // if (dot(r.direction(), normal) < 0) return false;            triangle.h:61
-        float dn = d.x * nx + d.y * ny + d.z * nz;
-        bool alive = !(dn < 0.0f);
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+    // if (dot(r.direction(), normal) < 0) return false;            triangle.h:61
+    float dn = d.x * nx + d.y * ny + d.z * nz;
+    bool alive = !(dn < 0.0f);
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
 
-        // h = cross(r.direction(), edge2); a = dot(edge1, h);            triangle.h:71-72
-        float hx = (d.y * e2z - d.z * e2y);
-        float hy = (-(d.x * e2z - d.z * e2x));
-        float hz = (d.x * e2y - d.y * e2x);
-        float a = e1x * hx + e1y * hy + e1z * hz;
-        // if (a > -EPSILON && a < EPSILON) return false;                triangle.h:77 (backCulling is false)
-        alive = alive && !(a > -kTriEpsilon && a < kTriEpsilon);
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+    // h = cross(r.direction(), edge2); a = dot(edge1, h);            triangle.h:71-72
+    float hx = (d.y * e2z - d.z * e2y);
+    float hy = (-(d.x * e2z - d.z * e2x));
+    float hz = (d.x * e2y - d.y * e2x);
+    float a = e1x * hx + e1y * hy + e1z * hz;
+    // if (a > -EPSILON && a < EPSILON) return false;                triangle.h:77 (backCulling is false)
+    alive = alive && !(a > -kTriEpsilon && a < kTriEpsilon);
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
 
-        float f = 1.0f / a;                     // f = 1.0 / a (double site, == fp32 IEEE divide), triangle.h:80
-        float u = f * (sx * hx + sy * hy + sz * hz);                      // triangle.h:82
-        alive = alive && !(u < 0.0f || u > 1.0f);                         // triangle.h:84
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+    float f = 1.0f / a;                     // f = 1.0 / a (double site, == fp32 IEEE divide), triangle.h:80
+    float u = f * (sx * hx + sy * hy + sz * hz);                      // triangle.h:82
+    alive = alive && !(u < 0.0f || u > 1.0f);                         // triangle.h:84
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
 
-        float v = f * (d.x * qx + d.y * qy + d.z * qz);                   // triangle.h:88
-        alive = alive && !(v < 0.0f || u + v > 1.0f);                     // triangle.h:89
-        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) continue;
+    float v = f * (d.x * qx + d.y * qy + d.z * qz);                   // triangle.h:88
+    alive = alive && !(v < 0.0f || u + v > 1.0f);                     // triangle.h:89
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
 
-        float t = f * tq;                                                 // triangle.h:92
-        // hit(...) && tmp_rec.t < closest_so_far                         hitable_list.h:84
-        if (alive && t < closest) {
-            closest = t;
-            hit_idx = i;
-        }
+    float t = f * tq;                                                 // triangle.h:92
+    // hit(...) && tmp_rec.t < closest_so_far                         hitable_list.h:84
+    if (alive && t < closest) {
+        closest = t;
+        hit_idx = i;
     }
 }
 
-// One lane = one pixel; one wavefront = an 8x8 pixel tile; one 256-thread block = 16x16.
-template <int VARIANT>
-__global__ void __launch_bounds__(256)
-render_list_kernel(RenderParams p, const float* __restrict__ rec,
-                   const float* __restrict__ shade_n, uint32_t* __restrict__ state,
-                   float* __restrict__ rgb) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);   // row inside the band
-    if (x >= p.nx || ly >= p.row_count) return;                        // render.h:109
+// The body of the `render` kernel for one pixel (core/render.h:105-129).  `traverse(d2,
+// closest, hit_idx)` must return the result of HitableList::collision_detection
+// (hitable/hitable_list.h:76-91): minimum t over all triangles that pass
+// Triangle::collision_detection (any sign of t, no range test), lowest index on ties, NaN
+// never accepted.
+template <class Traverse>
+__device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly,
+                                             const float* __restrict__ shade_n,
+                                             uint32_t* __restrict__ state, float* __restrict__ rgb,
+                                             Traverse traverse) {
     const int y = p.row_begin + ly;
     const long long pixel_index = (long long)y * p.nx + x;             // render.h:111 (global)
     const long long si = pixel_index - p.rng_first_pixel;              // element of this band's states
@@ -261,19 +267,16 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
             } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);          // dot(p,p) with p.z = 2*0-0
         }
         // direction = lower_left_corner + s*horizontal + t*vertical - origin - offset, offset = 0
-        V3 d0;
-        d0.x = ((c.llc[0] + u * c.horizontal[0]) + v * c.vertical[0]) - c.origin[0];
-        d0.y = ((c.llc[1] + u * c.horizontal[1]) + v * c.vertical[1]) - c.origin[1];
-        d0.z = ((c.llc[2] + u * c.horizontal[2]) + v * c.vertical[2]) - c.origin[2];
+        V3 d0 = camera_direction(c, u, v);
 
         // world list Transform then triangle Transform: ScaleRay normalises twice
         // (transform.h:50-54 via hitable.h:34 at both levels).
         V3 d1 = unit_vector(d0);
         V3 d2 = unit_vector(d1);
 
-        float closest;
-        int hit_idx;
-        closest_hit_list(rec, p.n_tris, d2, closest, hit_idx);
+        float closest = FLT_MAX;   // double closest_so_far = t_max (FLT_MAX), hitable_list.h:82
+        int hit_idx = -1;
+        traverse(d2, closest, hit_idx);
 
         V3 sky = sky_from_unit(d1);                                    // backgroundSky(r.direction())
         if (hit_idx >= 0) {                                            // LambertShade, render.h:75-83
@@ -324,14 +327,272 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
     state[5 * stride + si] = rs.v4;
 }
 
-hipError_t launch_render(const RenderParams& p, const float* d_rec, const float* d_shade_n,
-                         uint32_t* d_state, float* d_rgb, int variant, hipStream_t stream) {
+// ---------------------------------------------------------------- variant 0: brute force
+// One lane = one pixel; one wavefront = an 8x8 pixel tile; one 256-thread block = 16x16.
+// Every ray walks the whole list.
+__global__ void __launch_bounds__(256)
+render_list_kernel(RenderParams p, const float* __restrict__ rec,
+                   const float* __restrict__ shade_n, uint32_t* __restrict__ state,
+                   float* __restrict__ rgb) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);   // row inside the band
+    if (x >= p.nx || ly >= p.row_count) return;                        // render.h:109
+    const int n_tris = p.n_tris;
+    render_pixel(p, x, ly, shade_n, state, rgb, [&](V3 d2, float& closest, int& hit_idx) {
+        for (int i = 0; i < n_tris; ++i)
+            exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
+    });
+}
+
+// ---------------------------------------------------------------- variant 1: tiled
+// Same pixels, far fewer tests.  A triangle can only be hit by a ray of a screen rectangle
+// if the reference's own float predicates can pass for some direction of that rectangle.
+// The four quantities those predicates are built from — dn, a, su = dot(s,h),
+// dq = dot(d,q) — are linear forms of the direction, hence affine in the screen
+// coordinates (u,v) up to the positive factor 1/|d0| and up to rounding.  The prepass
+// stores the exact affine coefficients per triangle (computed in fp64); a rectangle is
+// classified with interval bounds of those forms plus a slack that covers every rounding
+// the reference's float evaluation can commit (DESIGN.md §4.4 has the derivation).
+//   phase A  (lane = triangle, 1024 threads): stream all classification records once per
+//            32x32 region, coalesced; survivors -> ordered LDS list.
+//   phase A2 (lane = list entry, per wave):   re-classify against the wave's own 8x8 tile.
+//   phase B  (lane = pixel):                  the reference arithmetic (exact_test) on the
+//            tile's survivors only, in ascending index order.
+constexpr int kRegion = 32;
+constexpr int kTiledThreads = 1024;
+constexpr int kTiledWaves = kTiledThreads / 64;
+constexpr int kK1Max = 8192;   // region list capacity (indices)
+constexpr int kK2Max = 704;    // per-tile list capacity
+
+struct TileBox {
+    float uc, hu, vc, hv;   // centre / half extent of the rectangle in (u,v)
+    float K;                // slack factor: kappa * max|d0|
+};
+
+// Bounds for the rays of pixels [x_lo,x_hi) x [y_lo,y_hi) (global pixel coordinates as
+// floats): u = fl((x + U)/nx) with fl(x + U) in [x_lo, x_hi], likewise v.
+__device__ __forceinline__ TileBox make_box(const CameraPOD& c, float x_lo, float x_hi, float y_lo,
+                                            float y_hi, float fnx, float fny) {
+    float u0 = x_lo / fnx, u1 = x_hi / fnx, v0 = y_lo / fny, v1 = y_hi / fny;
+    TileBox b;
+    b.uc = 0.5f * (u0 + u1);
+    b.vc = 0.5f * (v0 + v1);
+    b.hu = (u1 - u0) * 0.5f * 1.00001f + 1.0e-7f;
+    b.hv = (v1 - v0) * 0.5f * 1.00001f + 1.0e-7f;
+    // d0 is monotone in u and in v per component (every rounded operation is monotone), so
+    // its component ranges over the rectangle are attained at the four corners.
+    V3 c00 = camera_direction(c, u0, v0), c10 = camera_direction(c, u1, v0);
+    V3 c01 = camera_direction(c, u0, v1), c11 = camera_direction(c, u1, v1);
+    float lo[3] = {fminf(fminf(c00.x, c10.x), fminf(c01.x, c11.x)), fminf(fminf(c00.y, c10.y), fminf(c01.y, c11.y)),
+                   fminf(fminf(c00.z, c10.z), fminf(c01.z, c11.z))};
+    float hi[3] = {fmaxf(fmaxf(c00.x, c10.x), fmaxf(c01.x, c11.x)), fmaxf(fmaxf(c00.y, c10.y), fmaxf(c01.y, c11.y)),
+                   fmaxf(fmaxf(c00.z, c10.z), fmaxf(c01.z, c11.z))};
+    float s_hi = 0.0f, s_lo = 0.0f, mag = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float mx = fmaxf(fabsf(lo[k]), fabsf(hi[k]));
+        float mn = (lo[k] <= 0.0f && hi[k] >= 0.0f) ? 0.0f : fminf(fabsf(lo[k]), fabsf(hi[k]));
+        s_hi += mx * mx;
+        s_lo += mn * mn;
+        mag = fmaxf(mag, fabsf(c.llc[k]) + fabsf(c.horizontal[k]) + fabsf(c.vertical[k]) + fabsf(c.origin[k]));
+    }
+    float len_hi = sqrtf(s_hi) * 1.000001f;   // >= |d0| of every ray of the rectangle
+    float len_lo = sqrtf(s_lo) * 0.999999f;   // <= |d0|
+    float delta0 = mag * 4.76837158e-7f;      // 2^-21 * mag: abs. error of a d0 component vs the affine model
+    float kappa = 2.0f * (delta0 / len_lo) + 3.0517578125e-5f;   // 2*eta0 + 2^-15  (len_lo == 0 -> inf -> keep all)
+    b.K = kappa * len_hi * 1.001f;
+    return b;
+}
+
+// true = some ray of the rectangle may pass Triangle::collision_detection for this triangle
+// (NaN anywhere -> true).  p0..p3 are the four planes of the classification record.
+__device__ __forceinline__ bool may_hit(float4 p0, float4 p1, float4 p2, float4 p3, const TileBox& b) {
+    // centre value and radius of each form over the rectangle
+    float c_dn = __builtin_fmaf(b.vc, p0.z, __builtin_fmaf(b.uc, p0.y, p0.x));
+    float r_dn = __builtin_fmaf(b.hv, fabsf(p0.z), b.hu * fabsf(p0.y));
+    float c_a = __builtin_fmaf(b.vc, p1.z, __builtin_fmaf(b.uc, p1.y, p1.x));
+    float r_a = __builtin_fmaf(b.hv, fabsf(p1.z), b.hu * fabsf(p1.y));
+    float c_su = __builtin_fmaf(b.vc, p2.z, __builtin_fmaf(b.uc, p2.y, p2.x));
+    float r_su = __builtin_fmaf(b.hv, fabsf(p2.z), b.hu * fabsf(p2.y));
+    float c_dq = __builtin_fmaf(b.vc, p3.z, __builtin_fmaf(b.uc, p3.y, p3.x));
+    float r_dq = __builtin_fmaf(b.hv, fabsf(p3.z), b.hu * fabsf(p3.y));
+    // third barycentric numerator w = a - su - dq, as its own affine form (tight radius)
+    float Aw = p1.x - p2.x - p3.x, Bw = p1.y - p2.y - p3.y, Cw = p1.z - p2.z - p3.z;
+    float c_w = __builtin_fmaf(b.vc, Cw, __builtin_fmaf(b.uc, Bw, Aw));
+    float r_w = __builtin_fmaf(b.hv, fabsf(Cw), b.hu * fabsf(Bw));
+    // slacks (un-normalised units): K * M
+    float S_dn = b.K * p0.w, S_a = b.K * p1.w, S_su = b.K * p2.w, S_dq = b.K * p3.w;
+    float S_w = b.K * (p2.w + p3.w + 1.25f * p1.w);
+    // relative inflation of the radii covers the rounding of this very evaluation
+    r_dn = r_dn * 1.0001f; r_a = r_a * 1.0001f; r_su = r_su * 1.0001f; r_dq = r_dq * 1.0001f; r_w = r_w * 1.0001f;
+
+    bool cull_ok = !(c_dn + r_dn < -S_dn);                 // some ray may have dn >= 0
+    bool pos = !(c_a + r_a < -S_a) && !(c_su + r_su < -S_su) && !(c_dq + r_dq < -S_dq) && !(c_w + r_w < -S_w);
+    bool neg = !(c_a - r_a > S_a) && !(c_su - r_su > S_su) && !(c_dq - r_dq > S_dq) && !(c_w - r_w > S_w);
+    return cull_ok && (pos || neg);
+}
+
+__device__ __forceinline__ bool classify(const float4* __restrict__ cls, int n_pad, int idx, const TileBox& b) {
+    float4 p0 = cls[(size_t)0 * n_pad + idx];
+    float4 p1 = cls[(size_t)1 * n_pad + idx];
+    float4 p2 = cls[(size_t)2 * n_pad + idx];
+    float4 p3 = cls[(size_t)3 * n_pad + idx];
+    return may_hit(p0, p1, p2, p3, b);
+}
+
+__global__ void __launch_bounds__(kTiledThreads)
+render_tiled_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls,
+                    int n_pad, const float* __restrict__ shade_n, uint32_t* __restrict__ state,
+                    float* __restrict__ rgb, int k1_cap, int k2_cap) {
+    __shared__ uint32_t list1[kK1Max];
+    __shared__ uint32_t list2[kTiledWaves][kK2Max];
+    __shared__ int wcnt[kTiledWaves];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tris = p.n_tris;
+    const float fnx = (float)p.nx, fny = (float)p.ny;
+    const unsigned long long lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    // region = 32x32 pixels of the band; rows are global image rows
+    const int rx0 = blockIdx.x * kRegion;
+    const int ry0 = p.row_begin + blockIdx.y * kRegion;
+    const int rx1 = min(rx0 + kRegion, p.nx);
+    const int ry1 = min(ry0 + kRegion, p.row_begin + p.row_count);
+
+    // ---- phase A: all classification records against the region rectangle
+    TileBox rb = make_box(p.cam, (float)rx0, (float)rx1, (float)ry0, (float)ry1, fnx, fny);
+    int cnt1 = 0;
+    for (int base = 0; base < n_tris; base += kTiledThreads) {
+        const int t = base + tid;
+        bool s = (t < n_tris) && classify(cls, n_pad, t, rb);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
+        if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kTiledWaves; ++w) {
+            int cw = wcnt[w];
+            before += (w < wave) ? cw : 0;
+            total += cw;
+        }
+        if (s) {
+            int pos = cnt1 + before + __builtin_popcountll(m & lanemask_lt);
+            if (pos < k1_cap) list1[pos] = (uint32_t)t;
+        }
+        cnt1 += total;
+        __syncthreads();
+    }
+    const bool overflow1 = cnt1 > k1_cap;   // block-uniform
+
+    // ---- phase A2: the wave's own 8x8 tile
+    const int tx0 = rx0 + (wave & 3) * 8;
+    const int ty0 = ry0 + (wave >> 2) * 8;
+    if (tx0 >= rx1 || ty0 >= ry1) return;   // tile outside the image/band (no barrier below)
+    const int tx1 = min(tx0 + 8, rx1), ty1 = min(ty0 + 8, ry1);
+    TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
+    const int src_count = overflow1 ? n_tris : cnt1;
+    int cnt2 = 0;
+    for (int j = 0; j < src_count; j += 64) {
+        const int k = j + lane;
+        int idx = -1;
+        if (k < src_count) idx = overflow1 ? k : (int)list1[k];
+        bool s = (idx >= 0) && classify(cls, n_pad, idx, tb);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
+        if (s) {
+            int pos = cnt2 + __builtin_popcountll(m & lanemask_lt);
+            if (pos < k2_cap) list2[wave][pos] = (uint32_t)idx;
+        }
+        cnt2 += __builtin_popcountll(m);
+    }
+    const bool overflow2 = cnt2 > k2_cap;   // wave-uniform
+
+    // ---- phase B: lane = pixel
+    const int x = tx0 + (lane & 7);
+    const int y = ty0 + (lane >> 3);
+    if (x >= tx1 || y >= ty1) return;
+    const int ly = y - p.row_begin;
+    render_pixel(p, x, ly, shade_n, state, rgb, [&](V3 d2, float& closest, int& hit_idx) {
+        if (!overflow2) {
+            for (int k = 0; k < cnt2; ++k) {
+                const int idx = __builtin_amdgcn_readfirstlane((int)list2[wave][k]);
+                exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
+            }
+        } else if (!overflow1) {
+            for (int k = 0; k < cnt1; ++k) {
+                const int idx = __builtin_amdgcn_readfirstlane((int)list1[k]);
+                exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
+            }
+        } else {
+            for (int i = 0; i < n_tris; ++i)
+                exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
+        }
+    });
+}
+
+// Classification prepass: per triangle, the exact (fp64) affine coefficients of the four
+// forms over d0(u,v) = (llc - o) + u*H + v*V, rounded to fp32, and the magnitudes M.
+__global__ void __launch_bounds__(256)
+cls_prepass_kernel(const float* __restrict__ rec, int n, int n_pad, CameraPOD cam,
+                   float4* __restrict__ cls) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rec + (size_t)i * kRecFloats;
+    const double nx = r[0], ny = r[1], nz = r[2];
+    const double e2x = r[3], e2y = r[4], e2z = r[5];
+    const double e1x = r[6], e1y = r[7], e1z = r[8];
+    const double sx = r[9], sy = r[10], sz = r[11];
+    const double qx = r[12], qy = r[13], qz = r[14];
+    // a = e1.(d x e2) = d.(e2 x e1);  su = s.(d x e2) = d.(e2 x s);  dq = d.q
+    const double gax = e2y * e1z - e2z * e1y, gay = e2z * e1x - e2x * e1z, gaz = e2x * e1y - e2y * e1x;
+    const double gsx = e2y * sz - e2z * sy, gsy = e2z * sx - e2x * sz, gsz = e2x * sy - e2y * sx;
+    const double p0x = (double)cam.llc[0] - (double)cam.origin[0];
+    const double p0y = (double)cam.llc[1] - (double)cam.origin[1];
+    const double p0z = (double)cam.llc[2] - (double)cam.origin[2];
+    const double hx = cam.horizontal[0], hy = cam.horizontal[1], hz = cam.horizontal[2];
+    const double vx = cam.vertical[0], vy = cam.vertical[1], vz = cam.vertical[2];
+    auto form = [&](double gx, double gy, double gz, float M) {
+        return make_float4((float)(p0x * gx + p0y * gy + p0z * gz), (float)(hx * gx + hy * gy + hz * gz),
+                           (float)(vx * gx + vy * gy + vz * gz), M);
+    };
+    const float n1 = fabsf(r[0]) + fabsf(r[1]) + fabsf(r[2]);
+    const float e11 = fabsf(r[6]) + fabsf(r[7]) + fabsf(r[8]);
+    const float e21 = fabsf(r[3]) + fabsf(r[4]) + fabsf(r[5]);
+    const float s1 = fabsf(r[9]) + fabsf(r[10]) + fabsf(r[11]);
+    const float q1 = fabsf(r[12]) + fabsf(r[13]) + fabsf(r[14]);
+    const float Ma = e11 * e21 * 1.001f;
+    cls[(size_t)0 * n_pad + i] = form(nx, ny, nz, n1 * 1.001f);
+    cls[(size_t)1 * n_pad + i] = form(gax, gay, gaz, Ma);
+    cls[(size_t)2 * n_pad + i] = form(gsx, gsy, gsz, s1 * e21 * 1.001f + Ma * 9.5367431640625e-7f);
+    cls[(size_t)3 * n_pad + i] = form(qx, qy, qz, q1 * 1.001f + Ma * 9.5367431640625e-7f);
+}
+
+hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const CameraPOD& cam,
+                              float4* d_cls, hipStream_t stream) {
+    if (n_tris <= 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_tris + 255) / 256));
+    hipLaunchKernelGGL(cls_prepass_kernel, grid, block, 0, stream, d_rec, n_tris, n_pad, cam, d_cls);
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
+                         const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
+                         hipStream_t stream) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
-    dim3 block(256);
-    dim3 grid((unsigned)((p.nx + 15) / 16), (unsigned)((p.row_count + 15) / 16));
-    (void)variant;
-    hipLaunchKernelGGL(render_list_kernel<0>, grid, block, 0, stream, p, d_rec, d_shade_n, d_state,
-                       d_rgb);
+    if (variant == 0 || d_cls == nullptr) {
+        dim3 block(256);
+        dim3 grid((unsigned)((p.nx + 15) / 16), (unsigned)((p.row_count + 15) / 16));
+        hipLaunchKernelGGL(render_list_kernel, grid, block, 0, stream, p, d_rec, d_shade_n, d_state, d_rgb);
+    } else {
+        dim3 block(kTiledThreads);
+        dim3 grid((unsigned)((p.nx + kRegion - 1) / kRegion), (unsigned)((p.row_count + kRegion - 1) / kRegion));
+        int k1 = (variant == 2) ? 48 : kK1Max, k2 = (variant == 2) ? 5 : kK2Max;
+        hipLaunchKernelGGL(render_tiled_kernel, grid, block, 0, stream, p, d_rec, d_cls, n_pad, d_shade_n,
+                           d_state, d_rgb, k1, k2);
+    }
     return hipGetLastError();
 }
 

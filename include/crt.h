@@ -142,7 +142,11 @@ int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
                const crt_scene *scene, const crt_camera *camera, uint64_t seed,
                float *rgb_out);
 
-/* Kernel selection (diagnostics / A-B benchmarking): 0 = default. Returns previous. */
+/* Kernel selection (diagnostics / A-B benchmarking), per calling thread. 0 = auto (default:
+ * tiled when the scene and camera are finite and |coordinate| <= 2^38, else brute force),
+ * 1 = brute-force list walk, 2 = tiled, 3 = tiled with tiny survivor-list capacities (test
+ * hook for the overflow fallbacks).  All variants produce identical pixels.  Returns the
+ * previous value. */
 int crt_set_kernel_variant(int variant);
 
 /* Duration in milliseconds of the last crt_render_rows main kernel launched through this

@@ -21,6 +21,17 @@ def gpu(crt_built):
     return torch
 
 
+VARIANTS = {"brute": 1, "tiled": 2, "tiled_tinycaps": 3}
+
+
+@pytest.fixture(params=sorted(VARIANTS))
+def variant(request, gpu, crt_built):
+    """Every kernel variant must produce the same pixels (crt_set_kernel_variant)."""
+    prev = crt_built.crt_set_kernel_variant(VARIANTS[request.param])
+    yield request.param
+    crt_built.crt_set_kernel_variant(prev)
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
@@ -76,7 +87,7 @@ GOLDEN = {
 
 
 @pytest.mark.parametrize("name", sorted(GOLDEN))
-def test_render_matches_golden(gpu, golden_dir, name):
+def test_render_matches_golden(gpu, golden_dir, name, variant):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     nx, ny, spp = int(g["nx"]), int(g["ny"]), int(g["spp"])
     scene, cam = make(GOLDEN[name](), nx, ny)
@@ -94,7 +105,7 @@ def test_render_matches_golden(gpu, golden_dir, name):
 # ---------------------------------------------------------------- live oracle comparisons
 @pytest.mark.parametrize("seed,ntri,nx,ny,spp", [(1, 64, 40, 24, 3), (2, 200, 33, 17, 2), (3, 17, 16, 16, 8),
                                                  (4, 1, 9, 9, 2), (5, 500, 24, 40, 1)])
-def test_random_soup_matches_oracle(gpu, oracle, seed, ntri, nx, ny, spp):
+def test_random_soup_matches_oracle(gpu, oracle, variant, seed, ntri, nx, ny, spp):
     sc = scenes.random_soup(ntri, seed)
     scene, cam = make(sc, nx, ny)
     (rgb,), states = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
@@ -104,7 +115,7 @@ def test_random_soup_matches_oracle(gpu, oracle, seed, ntri, nx, ny, spp):
     assert np.array_equal(states[1:], np.concatenate([ost["d"][:, None], ost["v"]], axis=1)[1:])
 
 
-def test_ragged_sizes_and_empty_scene(gpu, oracle):
+def test_ragged_sizes_and_empty_scene(gpu, oracle, variant):
     # image sizes that are not multiples of the 16x16 block / 8x8 wave tile, and N = 0
     sc = scenes.cornell32()
     for nx, ny in [(1, 1), (7, 3), (17, 9), (31, 33)]:
@@ -122,7 +133,7 @@ def test_ragged_sizes_and_empty_scene(gpu, oracle):
     assert np.array_equal(bits(rgb), bits(ref))
 
 
-def test_frames_continue_the_rng_streams(gpu, oracle):
+def test_frames_continue_the_rng_streams(gpu, oracle, variant):
     """renderListAnimation keeps curand_state across frames (core/render.h:174-186)."""
     sc = scenes.displaced_sphere(6, 8)
     nx, ny, spp = 32, 24, 2
@@ -138,7 +149,7 @@ def test_frames_continue_the_rng_streams(gpu, oracle):
     assert np.array_equal(a, b)
 
 
-def test_row_bands_equal_full_image(gpu):
+def test_row_bands_equal_full_image(gpu, variant):
     sc = scenes.displaced_sphere(10, 12)
     nx, ny, spp = 100, 75, 2
     scene, cam = make(sc, nx, ny)
@@ -181,7 +192,7 @@ def test_aperture_is_rejected(gpu):
 
 
 # ---------------------------------------------------------------- BASELINE sizes
-def test_c2_full_size_matches_oracle(gpu, oracle):
+def test_c2_full_size_matches_oracle(gpu, oracle, variant):
     """configs[1]: 800x600, 16 spp, Cornell-32 — the oracle needs ~20 s for the full frame."""
     sc = scenes.cornell32()
     nx, ny, spp = 800, 600, 16
@@ -190,6 +201,72 @@ def test_c2_full_size_matches_oracle(gpu, oracle):
     w, ocam = oracle_pair(oracle, sc, nx, ny)
     ref, _ = oracle.render(w, ocam, nx, ny, spp)
     assert np.array_equal(bits(rgb), bits(ref))
+
+
+def _soup_scene(kind, seed):
+    """Adversarial geometry for the tiled classification: the camera sits inside the soup,
+    triangles pass through / behind / next to the eye, sizes span 6 orders of magnitude."""
+    rng = np.random.RandomState(seed)
+    if kind == "around_eye":
+        sc = scenes.random_soup(300, seed, extent=3.0, size=2.5, z_range=(-4.0, 4.0))
+    elif kind == "tiny_far":
+        sc = scenes.random_soup(400, seed, extent=30.0, size=0.02, z_range=(-80.0, -60.0))
+    elif kind == "huge":
+        sc = scenes.random_soup(40, seed, extent=50.0, size=400.0, z_range=(-300.0, 300.0))
+    elif kind == "mixed_scales":
+        a = scenes.random_soup(150, seed, extent=2.0, size=0.001, z_range=(-3.0, -1.0))
+        b = scenes.random_soup(150, seed + 1, extent=200.0, size=150.0, z_range=(-500.0, 100.0))
+        pts = np.concatenate([a["points"], b["points"]])
+        idx = np.concatenate([a["idx"], b["idx"] + len(a["points"])])
+        perm = rng.permutation(len(idx))
+        sc = dict(points=pts, idx=idx[perm], normals=None, index_base=0, camera=a["camera"])
+    elif kind == "random_normals":
+        sc = scenes.random_soup(200, seed)
+        sc["normals"] = rng.normal(size=(200, 3)).astype(np.float32)      # stored normals unrelated to geometry
+    elif kind == "offset_camera":
+        sc = scenes.random_soup(250, seed, extent=6.0, size=2.0, z_range=(-15.0, 5.0))
+        sc["points"] = (sc["points"] + np.array([1000.0, -2000.0, 500.0], np.float32)).astype(np.float32)
+        sc["camera"] = dict(lookfrom=(1000.0, -2000.0, 500.0), lookat=(1000.3, -2000.2, 499.0), vfov=75.0,
+                            aperture=0.0, focus=10.0)
+    else:
+        raise ValueError(kind)
+    return sc
+
+
+@pytest.mark.parametrize("kind", ["around_eye", "tiny_far", "huge", "mixed_scales", "random_normals", "offset_camera"])
+@pytest.mark.parametrize("seed", [11, 12])
+def test_tiled_equals_brute_force_and_oracle_on_adversarial_soups(gpu, oracle, crt_built, kind, seed):
+    sc = _soup_scene(kind, seed)
+    nx, ny, spp = 72, 56, 3
+    scene, cam = make(sc, nx, ny)
+    outs = {}
+    for name, v in VARIANTS.items():
+        prev = crt_built.crt_set_kernel_variant(v)
+        try:
+            (outs[name],), _ = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+        finally:
+            crt_built.crt_set_kernel_variant(prev)
+    w, ocam = oracle_pair(oracle, sc, nx, ny)
+    ref, _ = oracle.render(w, ocam, nx, ny, spp)
+    for name in outs:
+        assert np.array_equal(bits(outs[name]), bits(ref)), (kind, seed, name)
+
+
+def test_tiled_equals_brute_force_on_c3_frame(gpu, crt_built):
+    """Whole 1920x1080 frame, 100 k triangles, 2 spp: tiled == brute force, bit for bit."""
+    sc = scenes.bunny100k()
+    nx, ny, spp = 1920, 1080, 2
+    scene, cam = make(sc, nx, ny)
+    outs = []
+    for v in (1, 2):
+        prev = crt_built.crt_set_kernel_variant(v)
+        try:
+            (o,), st = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+        finally:
+            crt_built.crt_set_kernel_variant(prev)
+        outs.append((o, st))
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
+    assert np.array_equal(outs[0][1], outs[1][1])
 
 
 def test_c3_crop_and_band_properties(gpu, oracle):
