@@ -65,6 +65,7 @@ PROTOTYPES = {
     "crt_render": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.POINTER(CrtCamera), C.c_uint64, _fp]),
     "crt_set_kernel_variant": (C.c_int, [C.c_int]),
+    "crt_debug_tiled_stats": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "crt_last_kernel_ms": (C.c_float, []),
     "crt_to_rgba8": (None, [_fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "crt_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _fp]),

@@ -33,6 +33,7 @@ thread_local std::string g_err;
 thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 thread_local bool g_ev_valid = false;
 thread_local int g_variant = 0;
+thread_local unsigned long long* g_d_stats = nullptr;   // device counters when stats are enabled
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -443,9 +444,31 @@ int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* r
         HIP_TRY(crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p.cam, scene->d_cls, stream));
     HIP_TRY(hipEventRecord(g_ev_start, stream));
     HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
-                               d_rgb, kernel_variant, stream));
+                               d_rgb, kernel_variant, g_d_stats, stream));
     HIP_TRY(hipEventRecord(g_ev_stop, stream));
     g_ev_valid = true;
+    return CRT_OK;
+}
+
+int crt_debug_tiled_stats(int enable, uint64_t* out24) {
+    // Diagnostics: per-thread device counters filled by the tiled kernel (regions, sum/max of the
+    // region survivor count, region overflows, tiles, sum/max of the tile survivor count, tile
+    // overflows, then a log2 histogram of the tile survivor count).  enable=1 allocates/zeroes,
+    // enable=0 frees; out24 (nullable) receives the current values first.
+    if (out24) {
+        memset(out24, 0, crt::kStatsWords * sizeof(uint64_t));
+        if (g_d_stats) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(out24, g_d_stats, crt::kStatsWords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        }
+    }
+    if (enable) {
+        if (!g_d_stats) HIP_TRY(hipMalloc(&g_d_stats, crt::kStatsWords * sizeof(uint64_t)));
+        HIP_TRY(hipMemset(g_d_stats, 0, crt::kStatsWords * sizeof(uint64_t)));
+    } else if (g_d_stats) {
+        (void)hipFree(g_d_stats);
+        g_d_stats = nullptr;
+    }
     return CRT_OK;
 }
 

@@ -71,6 +71,7 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const C
 // overflow fallbacks).  d_cls may be null for variant 0.
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
-                         hipStream_t stream);
+                         unsigned long long* d_stats, hipStream_t stream);
+constexpr int kStatsWords = 24;
 
 }  // namespace crt

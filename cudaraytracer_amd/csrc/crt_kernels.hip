@@ -235,7 +235,7 @@ template <class Traverse>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly,
                                              const float* __restrict__ shade_n,
                                              uint32_t* __restrict__ state, float* __restrict__ rgb,
-                                             Traverse traverse) {
+                                             bool store, Traverse traverse) {
     const int y = p.row_begin + ly;
     const long long pixel_index = (long long)y * p.nx + x;             // render.h:111 (global)
     const long long si = pixel_index - p.rng_first_pixel;              // element of this band's states
@@ -314,6 +314,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
     coly = (coly > 1.0f) ? 1.0f : ((coly < 0.0f) ? 0.0f : coly);
     colz = (colz > 1.0f) ? 1.0f : ((colz < 0.0f) ? 0.0f : colz);
 
+    if (!store) return;
     const size_t o = ((size_t)ly * p.nx + x) * 3;
     rgb[o + 0] = colx;
     rgb[o + 1] = coly;
@@ -340,7 +341,7 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
     const int ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);   // row inside the band
     if (x >= p.nx || ly >= p.row_count) return;                        // render.h:109
     const int n_tris = p.n_tris;
-    render_pixel(p, x, ly, shade_n, state, rgb, [&](V3 d2, float& closest, int& hit_idx) {
+    render_pixel(p, x, ly, shade_n, state, rgb, true, [&](V3 d2, float& closest, int& hit_idx) {
         for (int i = 0; i < n_tris; ++i)
             exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
     });
@@ -365,6 +366,7 @@ constexpr int kTiledThreads = 1024;
 constexpr int kTiledWaves = kTiledThreads / 64;
 constexpr int kK1Max = 8192;   // region list capacity (indices)
 constexpr int kK2Max = 704;    // per-tile list capacity
+constexpr int kHeavyMin = 64;  // tiles with more survivors than this are traced by all 16 waves together
 
 struct TileBox {
     float uc, hu, vc, hv;   // centre / half extent of the rectangle in (u,v)
@@ -445,10 +447,14 @@ __device__ __forceinline__ bool classify(const float4* __restrict__ cls, int n_p
 __global__ void __launch_bounds__(kTiledThreads)
 render_tiled_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls,
                     int n_pad, const float* __restrict__ shade_n, uint32_t* __restrict__ state,
-                    float* __restrict__ rgb, int k1_cap, int k2_cap) {
+                    float* __restrict__ rgb, int k1_cap, int k2_cap, int heavy_min,
+                    unsigned long long* __restrict__ stats) {
     __shared__ uint32_t list1[kK1Max];
     __shared__ uint32_t list2[kTiledWaves][kK2Max];
     __shared__ int wcnt[kTiledWaves];
+    __shared__ int tile_cnt[kTiledWaves];
+    __shared__ float part_t[2][kTiledWaves][64];
+    __shared__ int part_i[2][kTiledWaves][64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -487,50 +493,115 @@ render_tiled_kernel(RenderParams p, const float* __restrict__ rec, const float4*
         __syncthreads();
     }
     const bool overflow1 = cnt1 > k1_cap;   // block-uniform
+    if (stats && tid == 0) {                // diagnostics only (crt_debug_tiled_stats)
+        atomicAdd(&stats[0], 1ull);
+        atomicAdd(&stats[1], (unsigned long long)cnt1);
+        atomicMax(&stats[2], (unsigned long long)cnt1);
+        atomicAdd(&stats[3], overflow1 ? 1ull : 0ull);
+    }
 
     // ---- phase A2: the wave's own 8x8 tile
     const int tx0 = rx0 + (wave & 3) * 8;
     const int ty0 = ry0 + (wave >> 2) * 8;
-    if (tx0 >= rx1 || ty0 >= ry1) return;   // tile outside the image/band (no barrier below)
+    const bool tile_valid = tx0 < rx1 && ty0 < ry1;   // else: tile outside the image/band
     const int tx1 = min(tx0 + 8, rx1), ty1 = min(ty0 + 8, ry1);
-    TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
-    const int src_count = overflow1 ? n_tris : cnt1;
     int cnt2 = 0;
-    for (int j = 0; j < src_count; j += 64) {
-        const int k = j + lane;
-        int idx = -1;
-        if (k < src_count) idx = overflow1 ? k : (int)list1[k];
-        bool s = (idx >= 0) && classify(cls, n_pad, idx, tb);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
-        if (s) {
-            int pos = cnt2 + __builtin_popcountll(m & lanemask_lt);
-            if (pos < k2_cap) list2[wave][pos] = (uint32_t)idx;
+    if (tile_valid) {
+        TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
+        const int src_count = overflow1 ? n_tris : cnt1;
+        for (int j = 0; j < src_count; j += 64) {
+            const int k = j + lane;
+            int idx = -1;
+            if (k < src_count) idx = overflow1 ? k : (int)list1[k];
+            bool s = (idx >= 0) && classify(cls, n_pad, idx, tb);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
+            if (s) {
+                int pos = cnt2 + __builtin_popcountll(m & lanemask_lt);
+                if (pos < k2_cap) list2[wave][pos] = (uint32_t)idx;
+            }
+            cnt2 += __builtin_popcountll(m);
         }
-        cnt2 += __builtin_popcountll(m);
     }
-    const bool overflow2 = cnt2 > k2_cap;   // wave-uniform
+    if (lane == 0) tile_cnt[wave] = tile_valid ? cnt2 : -1;
+    if (stats && lane == 0 && tile_valid) {
+        atomicAdd(&stats[4], 1ull);
+        atomicAdd(&stats[5], (unsigned long long)cnt2);
+        atomicMax(&stats[6], (unsigned long long)cnt2);
+        atomicAdd(&stats[7], cnt2 > k2_cap ? 1ull : 0ull);
+        int bucket = 0;
+        while ((cnt2 >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt2 in [2^(b-1), 2^b)
+        atomicAdd(&stats[8 + bucket], 1ull);
+    }
+    __syncthreads();
 
-    // ---- phase B: lane = pixel
-    const int x = tx0 + (lane & 7);
-    const int y = ty0 + (lane >> 3);
-    if (x >= tx1 || y >= ty1) return;
-    const int ly = y - p.row_begin;
-    render_pixel(p, x, ly, shade_n, state, rgb, [&](V3 d2, float& closest, int& hit_idx) {
-        if (!overflow2) {
-            for (int k = 0; k < cnt2; ++k) {
-                const int idx = __builtin_amdgcn_readfirstlane((int)list2[wave][k]);
-                exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
-            }
-        } else if (!overflow1) {
-            for (int k = 0; k < cnt1; ++k) {
-                const int idx = __builtin_amdgcn_readfirstlane((int)list1[k]);
-                exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
-            }
-        } else {
-            for (int i = 0; i < n_tris; ++i)
-                exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
+    // ---- phase B, light tiles: one wave per tile, lane = pixel
+    if (tile_valid && cnt2 <= heavy_min) {
+        const int x = tx0 + (lane & 7);
+        const int y = ty0 + (lane >> 3);
+        if (x < tx1 && y < ty1) {
+            render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, true,
+                         [&](V3 d2, float& closest, int& hit_idx) {
+                for (int k = 0; k < cnt2; ++k) {
+                    const int idx = __builtin_amdgcn_readfirstlane((int)list2[wave][k]);
+                    exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
+                }
+            });
         }
-    });
+    }
+
+    // ---- phase B, heavy tiles: all 16 waves share one tile.  Every wave traces the same 64
+    // rays against its own slice of the tile's list (slices ascend in index), the partial
+    // (t, index) minima are merged through LDS in slice order with the reference's strict
+    // `<`, and every wave replays the same shading / RNG so the streams stay in step.
+    for (int t = 0; t < kTiledWaves; ++t) {
+        const int c = tile_cnt[t];                       // block-uniform
+        if (c <= heavy_min) continue;                    // light or absent (-1)
+        const int mode = (c <= k2_cap) ? 0 : (overflow1 ? 2 : 1);   // 0: list2[t], 1: list1, 2: all triangles
+        const int n_src = (mode == 0) ? c : (mode == 1 ? cnt1 : n_tris);
+        const int per = (n_src + kTiledWaves - 1) / kTiledWaves;
+        const int k0 = min(n_src, wave * per), k1 = min(n_src, k0 + per);
+        const int hx0 = rx0 + (t & 3) * 8, hy0 = ry0 + (t >> 2) * 8;
+        const int hx1 = min(hx0 + 8, rx1), hy1 = min(hy0 + 8, ry1);
+        const int xr = hx0 + (lane & 7), yr = hy0 + (lane >> 3);
+        const bool lane_valid = xr < hx1 && yr < hy1;
+        const int x = min(xr, hx1 - 1), y = min(yr, hy1 - 1);   // lanes off the image replay a valid pixel
+        int parity = 0;
+        render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, lane_valid && wave == 0,
+                     [&](V3 d2, float& closest, int& hit_idx) {
+            if (mode == 0) {
+                for (int k = k0; k < k1; ++k) {
+                    const int idx = __builtin_amdgcn_readfirstlane((int)list2[t][k]);
+                    exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
+                }
+            } else if (mode == 1) {
+                for (int k = k0; k < k1; ++k) {
+                    const int idx = __builtin_amdgcn_readfirstlane((int)list1[k]);
+                    exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
+                }
+            } else {
+                for (int i = k0; i < k1; ++i)
+                    exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
+            }
+            part_t[parity][wave][lane] = closest;
+            part_i[parity][wave][lane] = hit_idx;
+            __syncthreads();
+            float best = FLT_MAX;
+            int best_i = -1;
+#pragma unroll
+            for (int w = 0; w < kTiledWaves; ++w) {
+                const float tw = part_t[parity][w][lane];
+                const int iw = part_i[parity][w][lane];
+                if (iw >= 0 && tw < best) {      // strict <: the lower slice (lower index) keeps ties
+                    best = tw;
+                    best_i = iw;
+                }
+            }
+            closest = best;
+            hit_idx = best_i;
+            parity ^= 1;
+        });
+        __syncthreads();   // partial buffers are reused by the next heavy tile
+    }
 }
 
 // Classification prepass: per triangle, the exact (fp64) affine coefficients of the four
@@ -580,7 +651,7 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const C
 
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
-                         hipStream_t stream) {
+                         unsigned long long* d_stats, hipStream_t stream) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     if (variant == 0 || d_cls == nullptr) {
         dim3 block(256);
@@ -590,8 +661,9 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         dim3 block(kTiledThreads);
         dim3 grid((unsigned)((p.nx + kRegion - 1) / kRegion), (unsigned)((p.row_count + kRegion - 1) / kRegion));
         int k1 = (variant == 2) ? 48 : kK1Max, k2 = (variant == 2) ? 5 : kK2Max;
+        int heavy = (variant == 2) ? 3 : kHeavyMin;   // tiles with more survivors are shared by all waves
         hipLaunchKernelGGL(render_tiled_kernel, grid, block, 0, stream, p, d_rec, d_cls, n_pad, d_shade_n,
-                           d_state, d_rgb, k1, k2);
+                           d_state, d_rgb, k1, k2, heavy, d_stats);
     }
     return hipGetLastError();
 }

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Print the tiled kernel's survivor statistics for the bench scene (run on the GPU box)."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from cudaraytracer_amd import _lib, api
+
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+obj = bench.build_scene_obj(tempfile.mkdtemp())
+scene = api.Scene.from_obj(obj, scale=1.0)
+cam = api.init_camera(bench.NX, bench.NY)
+st = api.SetCurandState(bench.NX, bench.NY)
+d = torch.zeros(bench.NX * bench.NY * 3, device="cuda")
+L = _lib.lib()
+L.crt_debug_tiled_stats(1, None)
+api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d)
+torch.cuda.synchronize()
+out = (C.c_uint64 * 24)()
+L.crt_debug_tiled_stats(0, out)
+o = list(out)
+print("regions %d  sum1 %d (avg %.1f) max1 %d overflow1 %d" % (o[0], o[1], o[1] / max(o[0], 1), o[2], o[3]))
+print("tiles %d  sum2 %d (avg %.1f) max2 %d overflow2 %d" % (o[4], o[5], o[5] / max(o[4], 1), o[6], o[7]))
+print("hist (bucket b: 2^(b-1) <= n < 2^b):", o[8:])
+print("kernel ms", api.last_kernel_ms())
