@@ -53,6 +53,50 @@ int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                           \
     } while (0)
 
+// Scratch of the tiled variant: per host thread, grow-only, reused by every frame.
+struct Workspace {
+    crt::TiledWork w{};
+    size_t pool_entries = 0, tiles = 0;
+    int n_cus = 0;
+};
+thread_local Workspace g_ws;
+
+int ensure_workspace(int nx, int rows) {
+    Workspace& ws = g_ws;
+    const int tiles_x = (nx + 7) / 8, tiles_y = (rows + 7) / 8;
+    const size_t tiles = (size_t)tiles_x * tiles_y;
+    const size_t want_pool = std::min<size_t>(std::max<size_t>((size_t)16 << 20, tiles * 256), (size_t)1 << 30);
+    if (!ws.n_cus) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&ws.n_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    if (!ws.w.counters) {
+        HIP_TRY(hipMalloc(&ws.w.counters, crt::kCtrWords * sizeof(uint32_t)));
+        ws.w.counters64 = reinterpret_cast<unsigned long long*>(ws.w.counters);
+    }
+    if (want_pool > ws.pool_entries) {
+        if (ws.w.pool) (void)hipFree(ws.w.pool);
+        ws.w.pool = nullptr;
+        HIP_TRY(hipMalloc(&ws.w.pool, want_pool * sizeof(uint32_t)));
+        ws.pool_entries = want_pool;
+    }
+    if (tiles > ws.tiles) {
+        if (ws.w.tile_desc) (void)hipFree(ws.w.tile_desc);
+        if (ws.w.queue) (void)hipFree(ws.w.queue);
+        ws.w.tile_desc = nullptr;
+        ws.w.queue = nullptr;
+        HIP_TRY(hipMalloc(&ws.w.tile_desc, tiles * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&ws.w.queue, 4 * tiles * sizeof(uint32_t)));
+        ws.tiles = tiles;
+    }
+    ws.w.pool_cap = (uint32_t)std::min<size_t>(ws.pool_entries, 0xfffffff0u);
+    ws.w.tiles_x = tiles_x;
+    ws.w.tiles_y = tiles_y;
+    ws.w.tiles_total = (int)tiles;
+    return CRT_OK;
+}
+
 bool have_device() {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -440,17 +484,21 @@ int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* r
         HIP_TRY(hipEventCreate(&g_ev_start));
         HIP_TRY(hipEventCreate(&g_ev_stop));
     }
-    if (kernel_variant != 0)
+    if (kernel_variant != 0) {
+        int rc = ensure_workspace(nx, row_count);
+        if (rc != CRT_OK) return rc;
         HIP_TRY(crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p.cam, scene->d_cls, stream));
+    }
     HIP_TRY(hipEventRecord(g_ev_start, stream));
     HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
-                               d_rgb, kernel_variant, g_d_stats, stream));
+                               d_rgb, kernel_variant, kernel_variant ? &g_ws.w : nullptr, g_ws.n_cus, g_d_stats,
+                               stream));
     HIP_TRY(hipEventRecord(g_ev_stop, stream));
     g_ev_valid = true;
     return CRT_OK;
 }
 
-int crt_debug_tiled_stats(int enable, uint64_t* out24) {
+int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords = 32 words
     // Diagnostics: per-thread device counters filled by the tiled kernel (regions, sum/max of the
     // region survivor count, region overflows, tiles, sum/max of the tile survivor count, tile
     // overflows, then a log2 histogram of the tile survivor count).  enable=1 allocates/zeroes,

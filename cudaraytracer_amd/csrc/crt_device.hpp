@@ -69,9 +69,23 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const C
 // variant 0: brute force (every ray x every triangle); 1: tiled (conservative region/tile
 // classification + exact test on survivors); 2: tiled with tiny list capacities (tests the
 // overflow fallbacks).  d_cls may be null for variant 0.
+// Scratch of the tiled variant (device pointers; owned by the host layer, grow-only).
+struct TiledWork {
+    uint32_t* pool;                  // survivor indices of all tiles, bump-allocated
+    unsigned long long* counters64;  // [0] pool cursor (entries)
+    uint32_t pool_cap;               // entries
+    uint2* tile_desc;                // per tile {pool offset, count | kNoList}
+    uint32_t* queue;                 // 4 weight classes x tiles_total tile ids
+    uint32_t* counters;              // kCtrQueueLen+c: queue length, kCtrCursor+c: consumer cursor
+    int tiles_x, tiles_y, tiles_total;
+};
+constexpr int kCtrQueueLen = 2;      // counters[0..1] alias counters64[0]
+constexpr int kCtrCursor = 8;
+constexpr int kCtrWords = 16;
+
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
-                         unsigned long long* d_stats, hipStream_t stream);
-constexpr int kStatsWords = 24;
+                         const TiledWork* work, int n_cus, unsigned long long* d_stats, hipStream_t stream);
+constexpr int kStatsWords = 32;
 
 }  // namespace crt

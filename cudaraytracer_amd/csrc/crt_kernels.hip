@@ -25,6 +25,8 @@
 
 #include <float.h>
 
+#include <algorithm>
+
 namespace crt {
 
 // ------------------------------------------------------------------ XORWOW (cuRAND)
@@ -365,8 +367,8 @@ constexpr int kRegion = 32;
 constexpr int kTiledThreads = 1024;
 constexpr int kTiledWaves = kTiledThreads / 64;
 constexpr int kK1Max = 8192;   // region list capacity (indices)
-constexpr int kK2Max = 704;    // per-tile list capacity
 constexpr int kHeavyMin = 64;  // tiles with more survivors than this are traced by all 16 waves together
+constexpr unsigned kNoList = 0xffffffffu;   // tile_desc.y: the pool was full, walk every triangle
 
 struct TileBox {
     float uc, hu, vc, hv;   // centre / half extent of the rectangle in (u,v)
@@ -444,17 +446,15 @@ __device__ __forceinline__ bool classify(const float4* __restrict__ cls, int n_p
     return may_hit(p0, p1, p2, p3, b);
 }
 
+// ---- kernel 1 of the tiled variant: binning.  One 1024-thread block per 32x32 region.
+// Output: for every 8x8 tile of the band its survivor list (ascending triangle indices) in
+// a global pool, a descriptor {offset, count}, and its id appended to one of four work
+// queues by weight class.
 __global__ void __launch_bounds__(kTiledThreads)
-render_tiled_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls,
-                    int n_pad, const float* __restrict__ shade_n, uint32_t* __restrict__ state,
-                    float* __restrict__ rgb, int k1_cap, int k2_cap, int heavy_min,
-                    unsigned long long* __restrict__ stats) {
+bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledWork w, int k1_cap,
+                 int heavy_min, unsigned long long* __restrict__ stats) {
     __shared__ uint32_t list1[kK1Max];
-    __shared__ uint32_t list2[kTiledWaves][kK2Max];
     __shared__ int wcnt[kTiledWaves];
-    __shared__ int tile_cnt[kTiledWaves];
-    __shared__ float part_t[2][kTiledWaves][64];
-    __shared__ int part_i[2][kTiledWaves][64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -480,9 +480,9 @@ render_tiled_kernel(RenderParams p, const float* __restrict__ rec, const float4*
         __syncthreads();
         int before = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < kTiledWaves; ++w) {
-            int cw = wcnt[w];
-            before += (w < wave) ? cw : 0;
+        for (int k = 0; k < kTiledWaves; ++k) {
+            int cw = wcnt[k];
+            before += (k < wave) ? cw : 0;
             total += cw;
         }
         if (s) {
@@ -492,7 +492,7 @@ render_tiled_kernel(RenderParams p, const float* __restrict__ rec, const float4*
         cnt1 += total;
         __syncthreads();
     }
-    const bool overflow1 = cnt1 > k1_cap;   // block-uniform
+    const bool overflow1 = cnt1 > k1_cap;   // block-uniform: region list truncated -> re-scan everything
     if (stats && tid == 0) {                // diagnostics only (crt_debug_tiled_stats)
         atomicAdd(&stats[0], 1ull);
         atomicAdd(&stats[1], (unsigned long long)cnt1);
@@ -500,107 +500,167 @@ render_tiled_kernel(RenderParams p, const float* __restrict__ rec, const float4*
         atomicAdd(&stats[3], overflow1 ? 1ull : 0ull);
     }
 
-    // ---- phase A2: the wave's own 8x8 tile
-    const int tx0 = rx0 + (wave & 3) * 8;
-    const int ty0 = ry0 + (wave >> 2) * 8;
-    const bool tile_valid = tx0 < rx1 && ty0 < ry1;   // else: tile outside the image/band
+    // ---- phase A2: the wave's own 8x8 tile; pass 0 counts, pass 1 writes to the pool
+    const int tile_x = blockIdx.x * 4 + (wave & 3);
+    const int tile_y = blockIdx.y * 4 + (wave >> 2);
+    if (tile_x >= w.tiles_x || tile_y >= w.tiles_y) return;   // tile outside the image/band (no barriers below)
+    const int tile_id = tile_y * w.tiles_x + tile_x;
+    const int tx0 = tile_x * 8, ty0 = p.row_begin + tile_y * 8;
     const int tx1 = min(tx0 + 8, rx1), ty1 = min(ty0 + 8, ry1);
+    TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
+    const int src_count = overflow1 ? n_tris : cnt1;
     int cnt2 = 0;
-    if (tile_valid) {
-        TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
-        const int src_count = overflow1 ? n_tris : cnt1;
+    unsigned long long off = 0;
+    bool fits = true;
+    for (int pass = 0; pass < 2; ++pass) {
+        int run = 0;
         for (int j = 0; j < src_count; j += 64) {
             const int k = j + lane;
             int idx = -1;
             if (k < src_count) idx = overflow1 ? k : (int)list1[k];
             bool s = (idx >= 0) && classify(cls, n_pad, idx, tb);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
-            if (s) {
-                int pos = cnt2 + __builtin_popcountll(m & lanemask_lt);
-                if (pos < k2_cap) list2[wave][pos] = (uint32_t)idx;
-            }
-            cnt2 += __builtin_popcountll(m);
+            if (pass == 1 && s) w.pool[off + (unsigned)(run + __builtin_popcountll(m & lanemask_lt))] = (uint32_t)idx;
+            run += __builtin_popcountll(m);
+        }
+        if (pass == 0) {
+            cnt2 = run;
+            unsigned long long o = 0;
+            if (lane == 0) o = atomicAdd(&w.counters64[0], (unsigned long long)cnt2);
+            off = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(o >> 32)) << 32) |
+                  (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)o);
+            fits = off + (unsigned long long)cnt2 <= (unsigned long long)w.pool_cap;
+            if (!fits || cnt2 == 0) break;
         }
     }
-    if (lane == 0) tile_cnt[wave] = tile_valid ? cnt2 : -1;
-    if (stats && lane == 0 && tile_valid) {
-        atomicAdd(&stats[4], 1ull);
-        atomicAdd(&stats[5], (unsigned long long)cnt2);
-        atomicMax(&stats[6], (unsigned long long)cnt2);
-        atomicAdd(&stats[7], cnt2 > k2_cap ? 1ull : 0ull);
-        int bucket = 0;
-        while ((cnt2 >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt2 in [2^(b-1), 2^b)
-        atomicAdd(&stats[8 + bucket], 1ull);
+    if (lane == 0) {
+        // weight class: 0 = no list (walk every triangle) or > 1024, 1 = > 256, 2 = > heavy_min, 3 = light
+        const unsigned weight = fits ? (unsigned)cnt2 : 0xffffffffu;
+        const int c = (weight > 1024u) ? 0 : (weight > 256u ? 1 : (weight > (unsigned)heavy_min ? 2 : 3));
+        w.tile_desc[tile_id] = make_uint2((unsigned)off, fits ? (unsigned)cnt2 : kNoList);
+        const unsigned pos = atomicAdd(&w.counters[kCtrQueueLen + c], 1u);
+        w.queue[(size_t)c * w.tiles_total + pos] = (uint32_t)tile_id;
+        if (stats) {
+            atomicAdd(&stats[4], 1ull);
+            atomicAdd(&stats[5], (unsigned long long)cnt2);
+            atomicMax(&stats[6], (unsigned long long)cnt2);
+            atomicAdd(&stats[7], fits ? 0ull : 1ull);
+            int bucket = 0;
+            while ((cnt2 >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt2 in [2^(b-1), 2^b)
+            atomicAdd(&stats[8 + bucket], 1ull);
+        }
     }
-    __syncthreads();
+}
 
-    // ---- phase B, light tiles: one wave per tile, lane = pixel
-    if (tile_valid && cnt2 <= heavy_min) {
-        const int x = tx0 + (lane & 7);
-        const int y = ty0 + (lane >> 3);
-        if (x < tx1 && y < ty1) {
+// ---- kernel 2 of the tiled variant: shading.  Persistent 1024-thread blocks pull tiles
+// from the work queues.  Heavy tiles (classes 0-2, heaviest first) are traced by all 16
+// waves of a block together: every wave traces the same 64 rays against its own slice of
+// the tile's list (slices ascend in index), the partial (t, index) minima are merged
+// through LDS in slice order with the reference's strict `<`, and every wave replays the
+// same shading / RNG so the streams stay in step.  Light tiles (class 3) are then pulled
+// one per wave.
+__global__ void __launch_bounds__(kTiledThreads, 8)
+shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* __restrict__ shade_n,
+                   uint32_t* __restrict__ state, float* __restrict__ rgb, TiledWork w,
+                   unsigned long long* __restrict__ stats) {
+    __shared__ float part_t[2][kTiledWaves][64];
+    __shared__ int part_i[2][kTiledWaves][64];
+    __shared__ unsigned s_item;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tris = p.n_tris;
+    const int band_y1 = p.row_begin + p.row_count;
+    const long long clk0 = stats ? (long long)clock64() : 0;
+
+    for (int c = 0; c < 3; ++c) {
+        const unsigned n_items = w.counters[kCtrQueueLen + c];
+        while (true) {
+            if (tid == 0) s_item = atomicAdd(&w.counters[kCtrCursor + c], 1u);
+            __syncthreads();
+            const unsigned item = s_item;
+            __syncthreads();
+            if (item >= n_items) break;
+            const int tile_id = (int)w.queue[(size_t)c * w.tiles_total + item];
+            const uint2 desc = w.tile_desc[tile_id];
+            const bool walk_all = desc.y == kNoList;
+            const int n_src = walk_all ? n_tris : (int)desc.y;
+            const uint32_t* __restrict__ lst = w.pool + desc.x;
+            const int per = (n_src + kTiledWaves - 1) / kTiledWaves;
+            const int k0 = min(n_src, wave * per), k1 = min(n_src, k0 + per);
+            const int hx0 = (tile_id % w.tiles_x) * 8, hy0 = p.row_begin + (tile_id / w.tiles_x) * 8;
+            const int hx1 = min(hx0 + 8, p.nx), hy1 = min(hy0 + 8, band_y1);
+            const int xr = hx0 + (lane & 7), yr = hy0 + (lane >> 3);
+            const bool lane_valid = xr < hx1 && yr < hy1;
+            const int x = min(xr, hx1 - 1), y = min(yr, hy1 - 1);   // lanes off the image replay a valid pixel
+            int parity = 0;
+            render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, lane_valid && wave == 0,
+                         [&](V3 d2, float& closest, int& hit_idx) {
+                if (!walk_all) {
+                    for (int k = k0; k < k1; ++k) {
+                        const int idx = __builtin_amdgcn_readfirstlane((int)lst[k]);
+                        exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
+                    }
+                } else {
+                    for (int i = k0; i < k1; ++i)
+                        exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
+                }
+                part_t[parity][wave][lane] = closest;
+                part_i[parity][wave][lane] = hit_idx;
+                __syncthreads();
+                float best = FLT_MAX;
+                int best_i = -1;
+#pragma unroll
+                for (int k = 0; k < kTiledWaves; ++k) {
+                    const float tw = part_t[parity][k][lane];
+                    const int iw = part_i[parity][k][lane];
+                    if (iw >= 0 && tw < best) {      // strict <: the lower slice (lower index) keeps ties
+                        best = tw;
+                        best_i = iw;
+                    }
+                }
+                closest = best;
+                hit_idx = best_i;
+                parity ^= 1;
+            });
+            __syncthreads();   // partial buffers are reused by the next tile
+        }
+    }
+    const long long clk1 = stats ? (long long)clock64() : 0;
+
+    // ---- light tiles: one wave per tile, lane = pixel
+    const unsigned n_light = w.counters[kCtrQueueLen + 3];
+    while (true) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(&w.counters[kCtrCursor + 3], 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_light) break;
+        const int tile_id = __builtin_amdgcn_readfirstlane((int)w.queue[(size_t)3 * w.tiles_total + item]);
+        const uint2 desc = w.tile_desc[tile_id];
+        const int cnt = __builtin_amdgcn_readfirstlane((int)desc.y);
+        const uint32_t* __restrict__ lst = w.pool + __builtin_amdgcn_readfirstlane(desc.x);
+        const int x0 = (tile_id % w.tiles_x) * 8, y0 = p.row_begin + (tile_id / w.tiles_x) * 8;
+        const int x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        if (x < p.nx && y < band_y1) {
             render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, true,
                          [&](V3 d2, float& closest, int& hit_idx) {
-                for (int k = 0; k < cnt2; ++k) {
-                    const int idx = __builtin_amdgcn_readfirstlane((int)list2[wave][k]);
+                for (int k = 0; k < cnt; ++k) {
+                    const int idx = __builtin_amdgcn_readfirstlane((int)lst[k]);
                     exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
                 }
             });
         }
     }
-
-    // ---- phase B, heavy tiles: all 16 waves share one tile.  Every wave traces the same 64
-    // rays against its own slice of the tile's list (slices ascend in index), the partial
-    // (t, index) minima are merged through LDS in slice order with the reference's strict
-    // `<`, and every wave replays the same shading / RNG so the streams stay in step.
-    for (int t = 0; t < kTiledWaves; ++t) {
-        const int c = tile_cnt[t];                       // block-uniform
-        if (c <= heavy_min) continue;                    // light or absent (-1)
-        const int mode = (c <= k2_cap) ? 0 : (overflow1 ? 2 : 1);   // 0: list2[t], 1: list1, 2: all triangles
-        const int n_src = (mode == 0) ? c : (mode == 1 ? cnt1 : n_tris);
-        const int per = (n_src + kTiledWaves - 1) / kTiledWaves;
-        const int k0 = min(n_src, wave * per), k1 = min(n_src, k0 + per);
-        const int hx0 = rx0 + (t & 3) * 8, hy0 = ry0 + (t >> 2) * 8;
-        const int hx1 = min(hx0 + 8, rx1), hy1 = min(hy0 + 8, ry1);
-        const int xr = hx0 + (lane & 7), yr = hy0 + (lane >> 3);
-        const bool lane_valid = xr < hx1 && yr < hy1;
-        const int x = min(xr, hx1 - 1), y = min(yr, hy1 - 1);   // lanes off the image replay a valid pixel
-        int parity = 0;
-        render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, lane_valid && wave == 0,
-                     [&](V3 d2, float& closest, int& hit_idx) {
-            if (mode == 0) {
-                for (int k = k0; k < k1; ++k) {
-                    const int idx = __builtin_amdgcn_readfirstlane((int)list2[t][k]);
-                    exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
-                }
-            } else if (mode == 1) {
-                for (int k = k0; k < k1; ++k) {
-                    const int idx = __builtin_amdgcn_readfirstlane((int)list1[k]);
-                    exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
-                }
-            } else {
-                for (int i = k0; i < k1; ++i)
-                    exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
-            }
-            part_t[parity][wave][lane] = closest;
-            part_i[parity][wave][lane] = hit_idx;
-            __syncthreads();
-            float best = FLT_MAX;
-            int best_i = -1;
-#pragma unroll
-            for (int w = 0; w < kTiledWaves; ++w) {
-                const float tw = part_t[parity][w][lane];
-                const int iw = part_i[parity][w][lane];
-                if (iw >= 0 && tw < best) {      // strict <: the lower slice (lower index) keeps ties
-                    best = tw;
-                    best_i = iw;
-                }
-            }
-            closest = best;
-            hit_idx = best_i;
-            parity ^= 1;
-        });
-        __syncthreads();   // partial buffers are reused by the next heavy tile
+    if (stats && lane == 0) {   // cycle accounting (diagnostics): heavy phase per block, light phase per wave
+        const long long clk2 = (long long)clock64();
+        if (wave == 0) {
+            atomicAdd(&stats[24], (unsigned long long)(clk1 - clk0));
+            atomicMax(&stats[25], (unsigned long long)(clk1 - clk0));
+        }
+        atomicAdd(&stats[26], (unsigned long long)(clk2 - clk1));
+        atomicMax(&stats[27], (unsigned long long)(clk2 - clk1));
+        atomicMax(&stats[28], (unsigned long long)(clk2 - clk0));
     }
 }
 
@@ -651,20 +711,28 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const C
 
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
-                         unsigned long long* d_stats, hipStream_t stream) {
+                         const TiledWork* work, int n_cus, unsigned long long* d_stats, hipStream_t stream) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
-    if (variant == 0 || d_cls == nullptr) {
+    if (variant == 0 || d_cls == nullptr || work == nullptr) {
         dim3 block(256);
         dim3 grid((unsigned)((p.nx + 15) / 16), (unsigned)((p.row_count + 15) / 16));
         hipLaunchKernelGGL(render_list_kernel, grid, block, 0, stream, p, d_rec, d_shade_n, d_state, d_rgb);
-    } else {
-        dim3 block(kTiledThreads);
-        dim3 grid((unsigned)((p.nx + kRegion - 1) / kRegion), (unsigned)((p.row_count + kRegion - 1) / kRegion));
-        int k1 = (variant == 2) ? 48 : kK1Max, k2 = (variant == 2) ? 5 : kK2Max;
-        int heavy = (variant == 2) ? 3 : kHeavyMin;   // tiles with more survivors are shared by all waves
-        hipLaunchKernelGGL(render_tiled_kernel, grid, block, 0, stream, p, d_rec, d_cls, n_pad, d_shade_n,
-                           d_state, d_rgb, k1, k2, heavy, d_stats);
+        return hipGetLastError();
     }
+    TiledWork w = *work;
+    if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
+    const int k1 = (variant == 2) ? 48 : kK1Max;
+    const int heavy = (variant == 2) ? 3 : kHeavyMin;    // tiles with more survivors are shared by all waves
+    hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    dim3 block(kTiledThreads);
+    dim3 grid_bin((unsigned)((p.nx + kRegion - 1) / kRegion), (unsigned)((p.row_count + kRegion - 1) / kRegion));
+    hipLaunchKernelGGL(bin_tiles_kernel, grid_bin, block, 0, stream, p, d_cls, n_pad, w, k1, heavy, d_stats);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    dim3 grid_shade((unsigned)std::max(1, std::min(n_cus * 2, w.tiles_total)));
+    hipLaunchKernelGGL(shade_tiles_kernel, grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state, d_rgb, w,
+                       d_stats);
     return hipGetLastError();
 }
 

@@ -149,11 +149,13 @@ int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
  * previous value. */
 int crt_set_kernel_variant(int variant);
 
-/* Diagnostics of the tiled variant, per calling thread.  out24 (nullable) first receives
+/* Diagnostics of the tiled variant, per calling thread.  out24 (nullable, 32 words) first receives
  * the counters accumulated since the last enable: [0] regions, [1] sum and [2] max of the
  * region survivor count, [3] region-list overflows, [4] tiles, [5] sum and [6] max of the
  * tile survivor count, [7] tile-list overflows, [8..23] histogram of the tile survivor count
- * (bucket b counts tiles with 2^(b-1) <= n < 2^b).  Then enable != 0 (re)starts counting,
+ * (bucket b counts tiles with 2^(b-1) <= n < 2^b), [24..27] summed block cycles (s_memtime) of
+ * phase A / A2 / B-light / B-heavy, [28..30] max block cycles total / B-light / B-heavy.
+ * Then enable != 0 (re)starts counting,
  * enable == 0 stops it.  Counting costs a few atomics per wavefront. */
 int crt_debug_tiled_stats(int enable, uint64_t *out24);
 
