@@ -25,6 +25,8 @@
 
 #include <float.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace crt {
@@ -188,14 +190,26 @@ __device__ __forceinline__ V3 sky_from_unit(V3 v) {
 // wave-uniform: the record arrives through scalar loads and feeds the VALU as SGPR operands;
 // after each of the reference's rejection tests the wavefront votes and leaves as soon as no
 // lane is alive.
-__device__ __forceinline__ void exact_test(const float* __restrict__ r, int i, V3 d,
-                                           float& closest, int& hit_idx) {
-    const float nx = r[0], ny = r[1], nz = r[2];
-    const float e2x = r[3], e2y = r[4], e2z = r[5];
-    const float e1x = r[6], e1y = r[7], e1z = r[8];
-    const float sx = r[9], sy = r[10], sz = r[11];
-    const float qx = r[12], qy = r[13], qz = r[14];
-    const float tq = r[15];
+struct Rec16 {
+    float f[kRecFloats];
+};
+
+// Wave-uniform address -> one s_load_dwordx16 into SGPRs.
+__device__ __forceinline__ Rec16 load_rec(const float* __restrict__ rec, int idx) {
+    const float* __restrict__ r = rec + (size_t)idx * kRecFloats;
+    Rec16 o;
+#pragma unroll
+    for (int k = 0; k < kRecFloats; ++k) o.f[k] = r[k];
+    return o;
+}
+
+__device__ __forceinline__ void exact_test(const Rec16& rc, int i, V3 d, float& closest, int& hit_idx) {
+    const float nx = rc.f[0], ny = rc.f[1], nz = rc.f[2];
+    const float e2x = rc.f[3], e2y = rc.f[4], e2z = rc.f[5];
+    const float e1x = rc.f[6], e1y = rc.f[7], e1z = rc.f[8];
+    const float sx = rc.f[9], sy = rc.f[10], sz = rc.f[11];
+    const float qx = rc.f[12], qy = rc.f[13], qz = rc.f[14];
+    const float tq = rc.f[15];
 
     // if (dot(r.direction(), normal) < 0) return false;            triangle.h:61
     float dn = d.x * nx + d.y * ny + d.z * nz;
@@ -225,6 +239,120 @@ __device__ __forceinline__ void exact_test(const float* __restrict__ r, int i, V
     if (alive && t < closest) {
         closest = t;
         hit_idx = i;
+    }
+}
+
+// exact_test over list positions [k0, k1); index_at(k) is the (wave-uniform) triangle index
+// of position k.  (A manual one-ahead prefetch of the next record was measured 1.75x SLOWER:
+// SMEM returns out of order, so hipcc must drain lgkmcnt to 0 before the first use of any
+// scalar-loaded register and then shuffles the record through s_mov copies.)
+template <class IndexAt>
+__device__ __forceinline__ void walk(const float* __restrict__ rec, int k0, int k1, IndexAt index_at,
+                                     V3 d, float& closest, int& hit_idx) {
+    for (int k = k0; k < k1; ++k) {
+        const int idx = index_at(k);
+        exact_test(load_rec(rec, idx), idx, d, closest, hit_idx);
+    }
+}
+
+// Same over a survivor list in global memory: 64 indices at a time are fetched with one
+// coalesced vector load (lane j holds position base+j) and handed out with v_readlane.
+__device__ __forceinline__ void walk_list(const float* __restrict__ rec, const uint32_t* __restrict__ lst,
+                                          int k0, int k1, int lane, V3 d, float& closest, int& hit_idx) {
+    for (int base = k0; base < k1; base += 64) {
+        const int n = min(64, k1 - base);
+        const int mine = (lane < n) ? (int)lst[base + lane] : 0;
+        walk(rec, 0, n, [&](int k) { return __builtin_amdgcn_readlane(mine, k); }, d, closest, hit_idx);
+    }
+}
+
+// ---- the same test with the record in VGPRs.  On gfx950 a VALU instruction with an SGPR
+// operand issues at half the rate of a VGPR-only one (profiles/r1_ubench_valu*.txt), so the
+// shading kernel of the tiled variant fetches the wave-uniform record with ordinary vector
+// loads from a uniform address (4 x global_load_dwordx4, a broadcast out of L1/L2; vmcnt is
+// in order, so the next record can stay in flight while this one is evaluated).
+struct RecV {
+    float4 a, b, c, d;   // n.xyz e2.x | e2.yz e1.xy | e1.z s.xyz | q.xyz tq
+};
+
+__device__ __forceinline__ RecV load_rec_v(const float* __restrict__ rec, int idx_uniform) {
+    int iv = idx_uniform;
+    asm volatile("" : "+v"(iv));   // opaque VGPR: keeps hipcc from turning this into scalar loads
+    const char* base = reinterpret_cast<const char*>(rec);
+    const float4* r = reinterpret_cast<const float4*>(base + (size_t)((unsigned)iv * (unsigned)(kRecFloats * 4)));
+    RecV o;
+    o.a = r[0];
+    o.b = r[1];
+    o.c = r[2];
+    o.d = r[3];
+    return o;
+}
+
+__device__ __forceinline__ void exact_test_v(const RecV& rc, int i, V3 d, float& closest, int& hit_idx) {
+    const float nx = rc.a.x, ny = rc.a.y, nz = rc.a.z;
+    const float e2x = rc.a.w, e2y = rc.b.x, e2z = rc.b.y;
+    const float e1x = rc.b.z, e1y = rc.b.w, e1z = rc.c.x;
+    const float sx = rc.c.y, sy = rc.c.z, sz = rc.c.w;
+    const float qx = rc.d.x, qy = rc.d.y, qz = rc.d.z;
+    const float tq = rc.d.w;
+
+    float dn = d.x * nx + d.y * ny + d.z * nz;                         // triangle.h:61
+    bool alive = !(dn < 0.0f);
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+
+    float hx = (d.y * e2z - d.z * e2y);                               // triangle.h:71-72
+    float hy = (-(d.x * e2z - d.z * e2x));
+    float hz = (d.x * e2y - d.y * e2x);
+    float a = e1x * hx + e1y * hy + e1z * hz;
+    alive = alive && !(a > -kTriEpsilon && a < kTriEpsilon);          // triangle.h:77
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+
+    float f = 1.0f / a;                                               // triangle.h:80
+    float u = f * (sx * hx + sy * hy + sz * hz);                      // triangle.h:82
+    alive = alive && !(u < 0.0f || u > 1.0f);                         // triangle.h:84
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+
+    float v = f * (d.x * qx + d.y * qy + d.z * qz);                   // triangle.h:88
+    alive = alive && !(v < 0.0f || u + v > 1.0f);                     // triangle.h:89
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+
+    float t = f * tq;                                                 // triangle.h:92
+    if (alive && t < closest) {                                       // hitable_list.h:84
+        closest = t;
+        hit_idx = i;
+    }
+}
+
+// exact_test_v over list positions [k0, k1), two alternating register sets, one record ahead.
+template <class IndexAt>
+__device__ __forceinline__ void walk_v(const float* __restrict__ rec, int k0, int k1, IndexAt index_at,
+                                       V3 d, float& closest, int& hit_idx) {
+    if (k0 >= k1) return;
+    int ia = index_at(k0), ib = 0;
+    RecV A = load_rec_v(rec, ia), B = A;
+    int k = k0;
+    while (true) {
+        if (k + 1 < k1) {
+            ib = index_at(k + 1);
+            B = load_rec_v(rec, ib);
+        }
+        exact_test_v(A, ia, d, closest, hit_idx);
+        if (++k >= k1) break;
+        if (k + 1 < k1) {
+            ia = index_at(k + 1);
+            A = load_rec_v(rec, ia);
+        }
+        exact_test_v(B, ib, d, closest, hit_idx);
+        if (++k >= k1) break;
+    }
+}
+
+__device__ __forceinline__ void walk_list_v(const float* __restrict__ rec, const uint32_t* __restrict__ lst,
+                                            int k0, int k1, int lane, V3 d, float& closest, int& hit_idx) {
+    for (int base = k0; base < k1; base += 64) {
+        const int n = min(64, k1 - base);
+        const int mine = (lane < n) ? (int)lst[base + lane] : 0;
+        walk_v(rec, 0, n, [&](int k) { return __builtin_amdgcn_readlane(mine, k); }, d, closest, hit_idx);
     }
 }
 
@@ -344,8 +472,7 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
     if (x >= p.nx || ly >= p.row_count) return;                        // render.h:109
     const int n_tris = p.n_tris;
     render_pixel(p, x, ly, shade_n, state, rgb, true, [&](V3 d2, float& closest, int& hit_idx) {
-        for (int i = 0; i < n_tris; ++i)
-            exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
+        walk(rec, 0, n_tris, [](int k) { return k; }, d2, closest, hit_idx);
     });
 }
 
@@ -367,7 +494,7 @@ constexpr int kRegion = 32;
 constexpr int kTiledThreads = 1024;
 constexpr int kTiledWaves = kTiledThreads / 64;
 constexpr int kK1Max = 8192;   // region list capacity (indices)
-constexpr int kHeavyMin = 64;  // tiles with more survivors than this are traced by all 16 waves together
+constexpr int kHeavyMin = 64;  // tiles with more survivors than this are traced by all 16 waves together (measured optimum, 16..128 swept)
 constexpr unsigned kNoList = 0xffffffffu;   // tile_desc.y: the pool was full, walk every triangle
 
 struct TileBox {
@@ -559,7 +686,8 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
 // through LDS in slice order with the reference's strict `<`, and every wave replays the
 // same shading / RNG so the streams stay in step.  Light tiles (class 3) are then pulled
 // one per wave.
-__global__ void __launch_bounds__(kTiledThreads, 8)
+template <bool VREC>
+__global__ void __launch_bounds__(kTiledThreads, VREC ? 4 : 8)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* __restrict__ shade_n,
                    uint32_t* __restrict__ state, float* __restrict__ rgb, TiledWork w,
                    unsigned long long* __restrict__ stats) {
@@ -597,14 +725,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             int parity = 0;
             render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, lane_valid && wave == 0,
                          [&](V3 d2, float& closest, int& hit_idx) {
-                if (!walk_all) {
-                    for (int k = k0; k < k1; ++k) {
-                        const int idx = __builtin_amdgcn_readfirstlane((int)lst[k]);
-                        exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
-                    }
+                if (VREC) {
+                    if (!walk_all) walk_list_v(rec, lst, k0, k1, lane, d2, closest, hit_idx);
+                    else walk_v(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
                 } else {
-                    for (int i = k0; i < k1; ++i)
-                        exact_test(rec + (size_t)i * kRecFloats, i, d2, closest, hit_idx);
+                    if (!walk_all) walk_list(rec, lst, k0, k1, lane, d2, closest, hit_idx);
+                    else walk(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
                 }
                 part_t[parity][wave][lane] = closest;
                 part_i[parity][wave][lane] = hit_idx;
@@ -642,12 +768,18 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
         const uint32_t* __restrict__ lst = w.pool + __builtin_amdgcn_readfirstlane(desc.x);
         const int x0 = (tile_id % w.tiles_x) * 8, y0 = p.row_begin + (tile_id / w.tiles_x) * 8;
         const int x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        // the whole list of a light tile fits one or two VGPRs (lane j holds positions j, 64+j)
+        const int mine0 = (lane < cnt) ? (int)lst[lane] : 0;
+        const int mine1 = (64 + lane < cnt) ? (int)lst[64 + lane] : 0;
         if (x < p.nx && y < band_y1) {
             render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, true,
                          [&](V3 d2, float& closest, int& hit_idx) {
-                for (int k = 0; k < cnt; ++k) {
-                    const int idx = __builtin_amdgcn_readfirstlane((int)lst[k]);
-                    exact_test(rec + (size_t)idx * kRecFloats, idx, d2, closest, hit_idx);
+                if (VREC) {
+                    walk_v(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
+                    walk_v(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
+                } else {
+                    walk(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
+                    walk(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
                 }
             });
         }
@@ -722,7 +854,10 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     TiledWork w = *work;
     if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
     const int k1 = (variant == 2) ? 48 : kK1Max;
-    const int heavy = (variant == 2) ? 3 : kHeavyMin;    // tiles with more survivors are shared by all waves
+    int heavy = (variant == 2) ? 3 : kHeavyMin;          // tiles with more survivors are shared by all waves
+    int blocks_per_cu = 2;
+    if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::min(atoi(e), 128);   // tuning hooks (not part of the ABI)
+    if (const char* e = getenv("CRT_SHADE_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(e));
     hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     dim3 block(kTiledThreads);
@@ -730,9 +865,13 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     hipLaunchKernelGGL(bin_tiles_kernel, grid_bin, block, 0, stream, p, d_cls, n_pad, w, k1, heavy, d_stats);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    dim3 grid_shade((unsigned)std::max(1, std::min(n_cus * 2, w.tiles_total)));
-    hipLaunchKernelGGL(shade_tiles_kernel, grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state, d_rgb, w,
-                       d_stats);
+    dim3 grid_shade((unsigned)std::max(1, std::min(n_cus * blocks_per_cu, w.tiles_total)));
+    if (variant != 3)
+        hipLaunchKernelGGL(shade_tiles_kernel<false>, grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
+                           d_rgb, w, d_stats);
+    else
+        hipLaunchKernelGGL(shade_tiles_kernel<true>, grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
+                           d_rgb, w, d_stats);
     return hipGetLastError();
 }
 

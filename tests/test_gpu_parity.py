@@ -21,7 +21,7 @@ def gpu(crt_built):
     return torch
 
 
-VARIANTS = {"brute": 1, "tiled": 2, "tiled_tinycaps": 3}
+VARIANTS = {"brute": 1, "tiled": 2, "tiled_tinycaps": 3, "tiled_vector_records": 4}
 
 
 @pytest.fixture(params=sorted(VARIANTS))
