@@ -42,13 +42,24 @@ def build_scene_obj(tmpdir):
     return path
 
 
-def algorithmic_bytes(nx, rows, spp, n_tris):
-    """Bytes one render launch must move if every 64-lane wavefront (8x8 pixel tile) reads
-    each 64-B triangle record once per sample, plus the float3 store and the XORWOW state
-    load/store (24 B each way) per pixel.  DESIGN.md §Roofline."""
+def algorithmic_bytes_brute(nx, rows, spp, n_tris):
+    """Brute-force variant: every 64-lane wavefront (8x8 pixel tile) reads each 64-B triangle
+    record once per sample, plus the float3 store and the XORWOW state load/store (24 B each
+    way) per pixel.  DESIGN.md §5."""
     tiles = ((nx + 7) // 8) * ((rows + 7) // 8)
     px = nx * rows
     return tiles * spp * n_tris * REC_BYTES + px * 12 + px * 48
+
+
+def algorithmic_bytes_tiled(nx, rows, spp, n_tris, regions, sum1, sum2):
+    """Tiled variant.  bin kernel: every 32x32 region streams all 64-B
+    classification records once, every tile re-reads its region's survivors twice (count +
+    write pass) and writes its list; shade kernel: every (tile, sample) reads the 64-B exact
+    record of each of the tile's survivors, the list once per tile, plus framebuffer + RNG."""
+    px = nx * rows
+    bin_b = regions * n_tris * REC_BYTES + 2 * 16 * sum1 * REC_BYTES + sum2 * 4
+    shade_b = spp * sum2 * REC_BYTES + sum2 * 4 + px * 12 + px * 48
+    return bin_b, shade_b
 
 
 def cpu_baseline(obj_path, budget_rays=1536):
@@ -140,7 +151,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(api.last_kernel_ms())             # HIP events on the launch stream
+        kernel_ms.append(api.last_kernel_times())          # HIP events on the launch stream
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -149,11 +160,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # survivor statistics of this rank's rows (one extra, untimed frame of the same shape, so
+    # that every launch a profiler sees is alike): they define the algorithmic bytes of the
+    # tiled kernels
+    api.tiled_stats(True)
+    br.render(args.spp, stream=stream)
+    torch.cuda.synchronize()
+    st = api.tiled_stats(False)
+    tiled = st[4] > 0
+
     if rank == 0:
         rays = NX * NY * args.spp * args.steps
         value = rays / elapsed / 1e6
-        k_ms = float(np.mean(kernel_ms))
-        alg = algorithmic_bytes(NX, br.row_count, args.spp, n_tris)
+        k_tot, k_bin, k_shade = [float(x) for x in np.mean(np.array(kernel_ms), axis=0)]
+        if tiled:
+            bin_b, shade_b = algorithmic_bytes_tiled(NX, br.row_count, args.spp, n_tris, st[0], st[1], st[5])
+            kernels = {
+                "bin_tiles_kernel": {"ms": k_bin, "algorithmic_bytes": bin_b, "GB/s": bin_b / (k_bin * 1e-3) / 1e9,
+                                     "note": "lane = triangle, coalesced stream of 64-B classification records, "
+                                             "once per 32x32 region (L2/MALL resident: %.1f MB)" % (n_tris * 64 / 1e6)},
+                "shade_tiles_kernel": {"ms": k_shade, "algorithmic_bytes": shade_b,
+                                       "GB/s": shade_b / (k_shade * 1e-3) / 1e9,
+                                       "note": "lane = pixel, exact reference arithmetic on tile survivors; "
+                                               "VALU-issue bound (DESIGN.md §5)"},
+            }
+            dom = "shade_tiles_kernel" if k_shade >= k_bin else "bin_tiles_kernel"
+            alg, k_ms = kernels[dom]["algorithmic_bytes"], kernels[dom]["ms"]
+            survivors = {"regions": st[0], "region_survivors_sum": st[1], "tiles": st[4],
+                         "tile_survivors_sum": st[5], "tile_survivors_max": st[6], "pool_overflows": st[7]}
+        else:
+            alg, k_ms, dom = algorithmic_bytes_brute(NX, br.row_count, args.spp, n_tris), k_tot, "render_list_kernel"
+            kernels, survivors = {"render_list_kernel": {"ms": k_tot, "algorithmic_bytes": alg}}, None
         achieved = alg / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs peak",
@@ -163,15 +200,17 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %dx%d, %d spp, %d-triangle synthetic OBJ mesh "
                                    "(displaced sphere; bunny.obj is absent from the reference), "
-                                   "brute-force triangle list, reference camera" % (NX, NY, args.spp, n_tris),
+                                   "triangle list (HitableList path), reference camera" % (NX, NY, args.spp, n_tris),
                        "nx": NX, "ny": NY, "spp": args.spp, "triangles": n_tris,
                        "parallelism": "row-bands x%d + 1 gather" % world,
                        "kernel_variant": args.variant},
-            "gtests_per_s": value * n_tris / 1e3,
-            "kernel_ms": k_ms,
+            "ray_triangle_pairs_per_s": value * 1e6 * n_tris,
+            "kernel_ms": k_tot,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "render_list_kernel", "algorithmic_bytes_per_launch": alg},
+                         "kernel": dom, "algorithmic_bytes_per_launch": alg},
+            "kernels": kernels,
+            "survivors": survivors,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(obj_path)

@@ -57,16 +57,21 @@ PROTOTYPES = {
     "crt_scene_free": (None, [C.c_void_p]),
     "crt_parse_obj": (C.c_int, [C.c_char_p, _fp, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crt_rng_create": (C.c_void_p, [C.c_int64, C.c_int64, C.c_uint64]),
+    "crt_rng_create_strips": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]),
+    "crt_strip_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "crt_rng_reset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "crt_rng_export": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "crt_rng_free": (None, [C.c_void_p]),
     "crt_render_rows": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "crt_render_strips": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "crt_render": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.POINTER(CrtCamera), C.c_uint64, _fp]),
     "crt_set_kernel_variant": (C.c_int, [C.c_int]),
     "crt_debug_tiled_stats": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "crt_last_kernel_ms": (C.c_float, []),
+    "crt_last_kernel_times": (C.c_int, [C.POINTER(C.c_float)]),
     "crt_to_rgba8": (None, [_fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "crt_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _fp]),
 }

@@ -114,9 +114,18 @@ def parse_obj(path):
 class CurandState:
     """curandState* curand_state of the reference for the pixels [first, first+count)."""
 
-    def __init__(self, first_pixel, count, seed=0):
+    def __init__(self, first_pixel, count, seed=0, _handle=None):
         self.first, self.count = int(first_pixel), int(count)
-        self.handle = check_handle(_lib.lib().crt_rng_create(self.first, self.count, int(seed)))
+        self.handle = _handle if _handle is not None else \
+            check_handle(_lib.lib().crt_rng_create(self.first, self.count, int(seed)))
+
+    @classmethod
+    def for_strips(cls, nx, ny, first_strip, strip_rows, strip_step, seed=0):
+        """States of the strips first_strip, first_strip+strip_step, ... (crt_rng_create_strips)."""
+        L = _lib.lib()
+        rows = L.crt_strip_rows(ny, first_strip, strip_rows, strip_step)
+        h = check_handle(L.crt_rng_create_strips(nx, ny, first_strip, strip_rows, strip_step, int(seed)))
+        return cls(first_strip * strip_rows * nx, rows * nx, seed, _handle=h)
 
     def reset(self, seed=0):
         check(_lib.lib().crt_rng_reset(self.handle, int(seed)))
@@ -159,11 +168,46 @@ def render_rows(scene, camera, curand_state, nx, ny, samples, row_begin, row_cou
                                      C.c_void_p(ptr), C.c_void_p(sptr)))
 
 
+def strip_rows(ny, first_strip, strip_rows_, strip_step):
+    return _lib.lib().crt_strip_rows(ny, first_strip, strip_rows_, strip_step)
+
+
+def render_strips(scene, camera, curand_state, nx, ny, samples, first_strip, strip_rows_, strip_step,
+                  d_rgb, max_depth=8, frame_index=0, stream=None):
+    """The render kernel on the strips first_strip, first_strip+strip_step, ... of strip_rows_
+    image rows each (crt_render_strips); d_rgb holds them strip after strip."""
+    ptr = d_rgb if isinstance(d_rgb, int) else d_rgb.data_ptr()
+    sptr = None
+    if stream is not None:
+        sptr = stream if isinstance(stream, int) else stream.cuda_stream
+    check(_lib.lib().crt_render_strips(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny,
+                                       samples, max_depth, frame_index, first_strip, strip_rows_, strip_step,
+                                       C.c_void_p(ptr), C.c_void_p(sptr)))
+
+
 def last_kernel_ms():
     ms = _lib.lib().crt_last_kernel_ms()
     if ms < 0:
         raise CrtError(_lib.CRT_ERR_HIP, _lib.lib().crt_last_error().decode())
     return ms
+
+
+def last_kernel_times():
+    """(total_ms, bin_ms, shade_ms) of the last render_rows on this thread."""
+    out = (C.c_float * 3)()
+    check(_lib.lib().crt_last_kernel_times(out))
+    return tuple(out)
+
+
+def tiled_stats(enable):
+    """crt_debug_tiled_stats: returns the 32 counters collected so far, then (re)starts or stops."""
+    out = (C.c_uint64 * 32)()
+    check(_lib.lib().crt_debug_tiled_stats(1 if enable else 0, out))
+    return list(out)
+
+
+def set_kernel_variant(v):
+    return _lib.lib().crt_set_kernel_variant(int(v))
 
 
 def render(nx, ny, samples, scene, camera, seed=0, max_depth=8, frame_index=0):

@@ -30,7 +30,8 @@
 namespace {
 
 thread_local std::string g_err;
-thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr, g_ev_mid = nullptr;
+thread_local bool g_ev_has_mid = false;
 thread_local bool g_ev_valid = false;
 thread_local int g_variant = 0;
 thread_local unsigned long long* g_d_stats = nullptr;   // device counters when stats are enabled
@@ -204,6 +205,7 @@ struct crt_scene {
 
 struct crt_rng {
     long long first = 0, count = 0;
+    int nx = 0, strip_rows = 1, strip_step = 1;   // layout (crt_rng_create_strips); contiguous when step == 1
     int device = 0;
     uint32_t* d_state = nullptr;  // SoA 6 x count: d, v0..v4
     uint32_t* d_jump = nullptr;
@@ -385,6 +387,46 @@ void crt_scene_free(crt_scene* s) {
     delete s;
 }
 
+namespace {
+// rows of the strips {row_begin/strip_rows + k*strip_step} that lie inside the image
+int strip_row_count(int ny, int row_begin, int strip_rows, int strip_step) {
+    int rows = 0;
+    for (long long y0 = row_begin; y0 < ny; y0 += (long long)strip_rows * strip_step)
+        rows += (int)std::min<long long>(strip_rows, ny - y0);
+    return rows;
+}
+}  // namespace
+
+crt_rng* crt_rng_create_strips(int nx, int ny, int first_strip, int strip_rows, int strip_step, uint64_t seed) {
+    if (nx <= 0 || ny <= 0 || first_strip < 0 || strip_rows <= 0 || strip_step <= 0 ||
+        (strip_step > 1 && strip_rows % 32 != 0) || (long long)first_strip * strip_rows >= ny) {
+        fail(CRT_ERR_INVALID, "crt_rng_create_strips: bad strip layout (strip_rows must be a multiple of 32)");
+        return nullptr;
+    }
+    const int row_begin = first_strip * strip_rows;
+    const int rows = strip_row_count(ny, row_begin, strip_rows, strip_step);
+    if (!have_device()) { fail(CRT_ERR_NO_DEVICE, "crt_rng_create_strips: no HIP device"); return nullptr; }
+    crt_rng* r = new (std::nothrow) crt_rng;
+    if (!r) { fail(CRT_ERR_NOMEM, "crt_rng_create_strips: out of memory"); return nullptr; }
+    r->first = (long long)row_begin * nx;
+    r->count = (long long)rows * nx;
+    r->nx = nx;
+    r->strip_rows = strip_rows;
+    r->strip_step = strip_step;
+    const std::vector<uint32_t>& jt = jump_table();
+    hipError_t e = hipGetDevice(&r->device);
+    if (e == hipSuccess) e = hipMalloc(&r->d_state, (size_t)r->count * 6 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&r->d_jump, jt.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(r->d_jump, jt.data(), jt.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        fail(CRT_ERR_HIP, "crt_rng_create_strips: %s", hipGetErrorString(e));
+        crt_rng_free(r);
+        return nullptr;
+    }
+    if (crt_rng_reset(r, seed) != CRT_OK) { crt_rng_free(r); return nullptr; }
+    return r;
+}
+
 crt_rng* crt_rng_create(int64_t first_pixel, int64_t count, uint64_t seed) {
     if (first_pixel < 0 || count <= 0) { fail(CRT_ERR_INVALID, "crt_rng_create: bad pixel range"); return nullptr; }
     if (!have_device()) { fail(CRT_ERR_NO_DEVICE, "crt_rng_create: no HIP device"); return nullptr; }
@@ -392,6 +434,7 @@ crt_rng* crt_rng_create(int64_t first_pixel, int64_t count, uint64_t seed) {
     if (!r) { fail(CRT_ERR_NOMEM, "crt_rng_create: out of memory"); return nullptr; }
     r->first = first_pixel;
     r->count = count;
+    r->nx = 1;   // contiguous range: element i is global pixel first_pixel + i
     const std::vector<uint32_t>& jt = jump_table();
     hipError_t e = hipGetDevice(&r->device);
     if (e == hipSuccess) e = hipMalloc(&r->d_state, (size_t)count * 6 * sizeof(uint32_t));
@@ -408,7 +451,8 @@ crt_rng* crt_rng_create(int64_t first_pixel, int64_t count, uint64_t seed) {
 
 int crt_rng_reset(crt_rng* r, uint64_t seed) {
     if (!r) return fail(CRT_ERR_INVALID, "crt_rng_reset: null handle");
-    HIP_TRY(crt::launch_rng_init(r->d_state, r->first, r->count, seed, r->d_jump, nullptr));
+    HIP_TRY(crt::launch_rng_init(r->d_state, r->first, r->count, r->nx, r->strip_rows, r->strip_step, seed,
+                                 r->d_jump, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     return CRT_OK;
 }
@@ -435,23 +479,56 @@ int crt_set_kernel_variant(int variant) {
     return prev;
 }
 
+namespace {
+int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny, int samples,
+                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_);
+}
+
 int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
                     int samples, int max_depth, int frame_index, int row_begin, int row_count,
                     float* d_rgb, void* stream_) {
     (void)max_depth;
     (void)frame_index;
-    if (!scene || !camera || !rng || !d_rgb) return fail(CRT_ERR_INVALID, "crt_render_rows: null argument");
     if (nx <= 0 || ny <= 0 || samples < 0 || row_begin < 0 || row_count <= 0 || row_begin + row_count > ny)
         return fail(CRT_ERR_INVALID, "crt_render_rows: bad image/row range (nx=%d ny=%d rows %d+%d)", nx, ny, row_begin, row_count);
+    return render_impl(scene, camera, rng, nx, ny, samples, row_begin, row_count, 32, 1, d_rgb, stream_);
+}
+
+int crt_render_strips(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
+                      int samples, int max_depth, int frame_index, int first_strip, int strip_rows,
+                      int strip_step, float* d_rgb, void* stream_) {
+    (void)max_depth;
+    (void)frame_index;
+    if (nx <= 0 || ny <= 0 || samples < 0 || first_strip < 0 || strip_rows <= 0 || strip_step <= 0 ||
+        (strip_step > 1 && strip_rows % 32 != 0) || (long long)first_strip * strip_rows >= ny)
+        return fail(CRT_ERR_INVALID, "crt_render_strips: bad strip layout (first %d, rows %d, step %d, ny %d)",
+                    first_strip, strip_rows, strip_step, ny);
+    const int row_begin = first_strip * strip_rows;
+    return render_impl(scene, camera, rng, nx, ny, samples, row_begin,
+                       strip_row_count(ny, row_begin, strip_rows, strip_step), strip_rows, strip_step, d_rgb, stream_);
+}
+
+int crt_strip_rows(int ny, int first_strip, int strip_rows, int strip_step) {
+    if (ny <= 0 || first_strip < 0 || strip_rows <= 0 || strip_step <= 0) return CRT_ERR_INVALID;
+    return strip_row_count(ny, first_strip * strip_rows, strip_rows, strip_step);
+}
+
+namespace {
+int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny, int samples,
+                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_) {
+    if (!scene || !camera || !rng || !d_rgb) return fail(CRT_ERR_INVALID, "crt_render_rows: null argument");
     if ((long long)nx * ny > 0x7fffffffLL)
         return fail(CRT_ERR_INVALID, "crt_render_rows: nx*ny exceeds the reference's int pixel_index (core/render.h:111)");
     if (camera->lens_radius != 0.0f)
         return fail(CRT_ERR_UNSUPPORTED,
                     "crt_render_rows: aperture != 0 is a data race on state[0] in the reference (core/render.h:118)");
     long long first = (long long)row_begin * nx, count = (long long)row_count * nx;
-    if (rng->first != first || rng->count != count)
-        return fail(CRT_ERR_INVALID, "crt_render_rows: rng covers pixels [%lld,+%lld), rows need [%lld,+%lld)",
-                    rng->first, rng->count, first, count);
+    const bool layout_ok = rng->first == first && rng->count == count &&
+                           (strip_step == 1 ? rng->strip_step == 1
+                                            : (rng->strip_step == strip_step && rng->strip_rows == strip_rows && rng->nx == nx));
+    if (!layout_ok)
+        return fail(CRT_ERR_INVALID, "crt_render_rows: rng covers pixels [%lld,+%lld) step %d, the rows need [%lld,+%lld) step %d",
+                    rng->first, rng->count, rng->strip_step, first, count, strip_step);
     hipStream_t stream = (hipStream_t)stream_;
 
     HIP_TRY(crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, scene->d_rec, stream));
@@ -477,13 +554,14 @@ int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* r
     memcpy(p.albedo, scene->albedo, 12);
     p.nx = nx; p.ny = ny; p.samples = samples;
     p.row_begin = row_begin; p.row_count = row_count;
+    p.strip_rows = strip_rows; p.strip_step = strip_step;
     p.n_tris = scene->n_tris;
-    p.rng_first_pixel = first;
     p.rng_count = count;
 
     if (!g_ev_start) {
         HIP_TRY(hipEventCreate(&g_ev_start));
         HIP_TRY(hipEventCreate(&g_ev_stop));
+        HIP_TRY(hipEventCreate(&g_ev_mid));
     }
     if (kernel_variant != 0) {
         int rc = ensure_workspace(nx, row_count);
@@ -493,11 +571,13 @@ int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* r
     HIP_TRY(hipEventRecord(g_ev_start, stream));
     HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
                                d_rgb, kernel_variant, kernel_variant ? &g_ws.w : nullptr, g_ws.n_cus, g_d_stats,
-                               stream));
+                               kernel_variant ? g_ev_mid : nullptr, stream));
+    g_ev_has_mid = kernel_variant != 0;
     HIP_TRY(hipEventRecord(g_ev_stop, stream));
     g_ev_valid = true;
     return CRT_OK;
 }
+}  // namespace
 
 int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords = 32 words
     // Diagnostics: per-thread device counters filled by the tiled kernel (regions, sum/max of the
@@ -517,6 +597,23 @@ int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords =
     } else if (g_d_stats) {
         (void)hipFree(g_d_stats);
         g_d_stats = nullptr;
+    }
+    return CRT_OK;
+}
+
+int crt_last_kernel_times(float* ms3) {
+    // ms3[0] = all render kernels of the last crt_render_rows, ms3[1] = binning kernel,
+    // ms3[2] = shading kernel (tiled variant) or the brute-force kernel; HIP events on the
+    // launch stream.
+    if (!ms3) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: null output");
+    if (!g_ev_valid) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: no kernel launched on this thread");
+    HIP_TRY(hipEventSynchronize(g_ev_stop));
+    HIP_TRY(hipEventElapsedTime(&ms3[0], g_ev_start, g_ev_stop));
+    ms3[1] = 0.0f;
+    ms3[2] = ms3[0];
+    if (g_ev_has_mid) {
+        HIP_TRY(hipEventElapsedTime(&ms3[1], g_ev_start, g_ev_mid));
+        HIP_TRY(hipEventElapsedTime(&ms3[2], g_ev_mid, g_ev_stop));
     }
     return CRT_OK;
 }

@@ -43,15 +43,22 @@ struct CameraPOD {
     float llc[3], horizontal[3], vertical[3], origin[3];
 };
 
+// The rows a launch renders ("local rows" 0..row_count) are strips of `strip_rows` image rows:
+// local row ly is image row  row_begin + (ly / strip_rows) * strip_rows * strip_step + ly % strip_rows.
+// strip_step == 1 is a contiguous band; strip_step == W deals strips round-robin to W ranks.
 struct RenderParams {
     CameraPOD cam;
     float albedo[3];
     int nx, ny, samples;
     int row_begin, row_count;
+    int strip_rows, strip_step;
     int n_tris;
-    long long rng_first_pixel;   // global pixel index of rng state element 0
-    long long rng_count;         // number of states (SoA stride)
+    long long rng_count;         // number of states = row_count * nx (SoA stride); element = ly * nx + x
 };
+
+__host__ __device__ inline int global_row(int row_begin, int strip_rows, int strip_step, int ly) {
+    return row_begin + (ly / strip_rows) * strip_rows * strip_step + ly % strip_rows;
+}
 
 // XORWOW jump table: J_k = T^(2^(67+k)), k = 0..63; row-vector convention,
 // 160 rows x 5 words per matrix.
@@ -60,8 +67,10 @@ constexpr int kXwBits = 160;
 constexpr int kXwJumps = 64;
 
 // Launchers (defined in crt_kernels.hip).
-hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long count,
-                           uint64_t seed, const uint32_t* d_jump, hipStream_t stream);
+// States of `count` pixels: element i is pixel x = i % nx of local row ly = i / nx, whose
+// global pixel index is first_pixel + global_row(0, strip_rows, strip_step, ly) * nx + x.
+hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long count, int nx, int strip_rows,
+                           int strip_step, uint64_t seed, const uint32_t* d_jump, hipStream_t stream);
 hipError_t launch_tri_prepass(const float* d_base, int n_tris, const float origin[3],
                               float* d_rec, hipStream_t stream);
 hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const CameraPOD& cam,
@@ -86,7 +95,8 @@ constexpr int kCtrWords = 16;
 
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
-                         const TiledWork* work, int n_cus, unsigned long long* d_stats, hipStream_t stream);
+                         const TiledWork* work, int n_cus, unsigned long long* d_stats, hipEvent_t ev_mid,
+                         hipStream_t stream);
 constexpr int kStatsWords = 32;
 
 }  // namespace crt

@@ -60,11 +60,17 @@ __device__ __forceinline__ float xw_uniform(Xorwow& s) {
 // J_k = T^(2^(67+k)), one per set bit of pixel_index.  Matrix rows are wave-uniform
 // scalar loads; each lane masks them with its own state bits.
 __global__ void __launch_bounds__(256)
-rng_init_kernel(uint32_t* __restrict__ state, long long first_pixel, long long count,
-                uint32_t seed_lo, uint32_t seed_hi, const uint32_t* __restrict__ jump, int nbits) {
+rng_init_kernel(uint32_t* __restrict__ state, long long first_pixel, int nx, int strip_rows, int strip_step,
+                long long count, uint32_t seed_lo, uint32_t seed_hi, const uint32_t* __restrict__ jump,
+                int nbits) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = i < count;
-    unsigned long long pi = (unsigned long long)(first_pixel + (live ? i : 0));
+    const long long il = live ? i : 0;
+    const int ly = (int)(il / nx), x = (int)(il % nx);
+    // subsequence = GLOBAL pixel index y*nx + x (deviceManage.h:126-127)
+    unsigned long long pi = (unsigned long long)first_pixel +
+                            (unsigned long long)global_row(0, strip_rows, strip_step, ly) * (unsigned long long)nx +
+                            (unsigned long long)x;
 
     // _curand_init_scratch seed scrambling
     uint32_t s0 = seed_lo ^ 0xaad26b49u;
@@ -109,15 +115,17 @@ rng_init_kernel(uint32_t* __restrict__ state, long long first_pixel, long long c
     }
 }
 
-hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long count,
-                           uint64_t seed, const uint32_t* d_jump, hipStream_t stream) {
-    if (count <= 0) return hipSuccess;
-    unsigned long long last = (unsigned long long)(first_pixel + count - 1);
+hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long count, int nx, int strip_rows,
+                           int strip_step, uint64_t seed, const uint32_t* d_jump, hipStream_t stream) {
+    if (count <= 0 || nx <= 0) return hipSuccess;
+    const int last_ly = (int)((count - 1) / nx);
+    unsigned long long last = (unsigned long long)first_pixel +
+                              (unsigned long long)(global_row(0, strip_rows, strip_step, last_ly) + 1) * (unsigned long long)nx;
     int nbits = 0;
     while (nbits < kXwJumps && (last >> nbits) != 0ull) ++nbits;
     dim3 block(256), grid((unsigned)((count + 255) / 256));
-    hipLaunchKernelGGL(rng_init_kernel, grid, block, 0, stream, d_state, first_pixel, count,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), d_jump, nbits);
+    hipLaunchKernelGGL(rng_init_kernel, grid, block, 0, stream, d_state, first_pixel, nx, strip_rows, strip_step,
+                       count, (uint32_t)seed, (uint32_t)(seed >> 32), d_jump, nbits);
     return hipGetLastError();
 }
 
@@ -366,9 +374,9 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
                                              const float* __restrict__ shade_n,
                                              uint32_t* __restrict__ state, float* __restrict__ rgb,
                                              bool store, Traverse traverse) {
-    const int y = p.row_begin + ly;
+    const int y = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
     const long long pixel_index = (long long)y * p.nx + x;             // render.h:111 (global)
-    const long long si = pixel_index - p.rng_first_pixel;              // element of this band's states
+    const long long si = (long long)ly * p.nx + x;                     // element of this launch's states
     const long long stride = p.rng_count;
 
     Xorwow rs;
@@ -590,11 +598,13 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
     const float fnx = (float)p.nx, fny = (float)p.ny;
     const unsigned long long lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    // region = 32x32 pixels of the band; rows are global image rows
+    // region = 32x32 pixels: 32 local rows (never straddles a strip: strip_rows % 32 == 0 or
+    // strip_step == 1); ry* are global image rows
     const int rx0 = blockIdx.x * kRegion;
-    const int ry0 = p.row_begin + blockIdx.y * kRegion;
+    const int rly0 = blockIdx.y * kRegion;
+    const int ry0 = global_row(p.row_begin, p.strip_rows, p.strip_step, rly0);
     const int rx1 = min(rx0 + kRegion, p.nx);
-    const int ry1 = min(ry0 + kRegion, p.row_begin + p.row_count);
+    const int ry1 = ry0 + min(kRegion, p.row_count - rly0);
 
     // ---- phase A: all classification records against the region rectangle
     TileBox rb = make_box(p.cam, (float)rx0, (float)rx1, (float)ry0, (float)ry1, fnx, fny);
@@ -632,7 +642,7 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
     const int tile_y = blockIdx.y * 4 + (wave >> 2);
     if (tile_x >= w.tiles_x || tile_y >= w.tiles_y) return;   // tile outside the image/band (no barriers below)
     const int tile_id = tile_y * w.tiles_x + tile_x;
-    const int tx0 = tile_x * 8, ty0 = p.row_begin + tile_y * 8;
+    const int tx0 = tile_x * 8, ty0 = ry0 + (wave >> 2) * 8;
     const int tx1 = min(tx0 + 8, rx1), ty1 = min(ty0 + 8, ry1);
     TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
     const int src_count = overflow1 ? n_tris : cnt1;
@@ -699,7 +709,6 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tris = p.n_tris;
-    const int band_y1 = p.row_begin + p.row_count;
     const long long clk0 = stats ? (long long)clock64() : 0;
 
     for (int c = 0; c < 3; ++c) {
@@ -717,13 +726,14 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             const uint32_t* __restrict__ lst = w.pool + desc.x;
             const int per = (n_src + kTiledWaves - 1) / kTiledWaves;
             const int k0 = min(n_src, wave * per), k1 = min(n_src, k0 + per);
-            const int hx0 = (tile_id % w.tiles_x) * 8, hy0 = p.row_begin + (tile_id / w.tiles_x) * 8;
-            const int hx1 = min(hx0 + 8, p.nx), hy1 = min(hy0 + 8, band_y1);
-            const int xr = hx0 + (lane & 7), yr = hy0 + (lane >> 3);
-            const bool lane_valid = xr < hx1 && yr < hy1;
-            const int x = min(xr, hx1 - 1), y = min(yr, hy1 - 1);   // lanes off the image replay a valid pixel
+            // local rows of the tile (tiles are 8 local rows; they never straddle a strip)
+            const int hx0 = (tile_id % w.tiles_x) * 8, hly0 = (tile_id / w.tiles_x) * 8;
+            const int hx1 = min(hx0 + 8, p.nx), hly1 = min(hly0 + 8, p.row_count);
+            const int xr = hx0 + (lane & 7), lyr = hly0 + (lane >> 3);
+            const bool lane_valid = xr < hx1 && lyr < hly1;
+            const int x = min(xr, hx1 - 1), ly = min(lyr, hly1 - 1);   // lanes off the image replay a valid pixel
             int parity = 0;
-            render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, lane_valid && wave == 0,
+            render_pixel(p, x, ly, shade_n, state, rgb, lane_valid && wave == 0,
                          [&](V3 d2, float& closest, int& hit_idx) {
                 if (VREC) {
                     if (!walk_all) walk_list_v(rec, lst, k0, k1, lane, d2, closest, hit_idx);
@@ -766,13 +776,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
         const uint2 desc = w.tile_desc[tile_id];
         const int cnt = __builtin_amdgcn_readfirstlane((int)desc.y);
         const uint32_t* __restrict__ lst = w.pool + __builtin_amdgcn_readfirstlane(desc.x);
-        const int x0 = (tile_id % w.tiles_x) * 8, y0 = p.row_begin + (tile_id / w.tiles_x) * 8;
-        const int x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        const int x0 = (tile_id % w.tiles_x) * 8, ly0 = (tile_id / w.tiles_x) * 8;
+        const int x = x0 + (lane & 7), ly = ly0 + (lane >> 3);
         // the whole list of a light tile fits one or two VGPRs (lane j holds positions j, 64+j)
         const int mine0 = (lane < cnt) ? (int)lst[lane] : 0;
         const int mine1 = (64 + lane < cnt) ? (int)lst[64 + lane] : 0;
-        if (x < p.nx && y < band_y1) {
-            render_pixel(p, x, y - p.row_begin, shade_n, state, rgb, true,
+        if (x < p.nx && ly < p.row_count) {
+            render_pixel(p, x, ly, shade_n, state, rgb, true,
                          [&](V3 d2, float& closest, int& hit_idx) {
                 if (VREC) {
                     walk_v(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
@@ -843,7 +853,8 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const C
 
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
-                         const TiledWork* work, int n_cus, unsigned long long* d_stats, hipStream_t stream) {
+                         const TiledWork* work, int n_cus, unsigned long long* d_stats, hipEvent_t ev_mid,
+                         hipStream_t stream) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     if (variant == 0 || d_cls == nullptr || work == nullptr) {
         dim3 block(256);
@@ -865,6 +876,10 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     hipLaunchKernelGGL(bin_tiles_kernel, grid_bin, block, 0, stream, p, d_cls, n_pad, w, k1, heavy, d_stats);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (ev_mid) {
+        e = hipEventRecord(ev_mid, stream);   // splits the timing: [start, mid) = binning, [mid, stop) = shading
+        if (e != hipSuccess) return e;
+    }
     dim3 grid_shade((unsigned)std::max(1, std::min(n_cus * blocks_per_cu, w.tiles_total)));
     if (variant != 3)
         hipLaunchKernelGGL(shade_tiles_kernel<false>, grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,

@@ -107,6 +107,14 @@ int crt_parse_obj(const char *path, float *points, float *idx3f, int *n_points, 
  * them like curand_init(seed, pixel_index, 0, &state[pixel_index]).  A rank that renders
  * a row band passes first_pixel = row_begin*nx, count = rows*nx. */
 crt_rng *crt_rng_create(int64_t first_pixel, int64_t count, uint64_t seed);
+/* Same for a rank that renders strips of `strip_rows` image rows dealt round-robin: strips
+ * first_strip, first_strip + strip_step, ... (strip s covers rows [s*strip_rows,
+ * (s+1)*strip_rows) clipped to ny).  States are stored strip after strip, row-major, like
+ * the colour buffer of crt_render_strips.  strip_rows must be a multiple of 32. */
+crt_rng *crt_rng_create_strips(int nx, int ny, int first_strip, int strip_rows, int strip_step,
+                               uint64_t seed);
+/* Number of image rows in that strip set (what the rank's buffers must hold). */
+int crt_strip_rows(int ny, int first_strip, int strip_rows, int strip_step);
 /* Re-run the initialisation (same as a fresh crt_rng_create). */
 int crt_rng_reset(crt_rng *rng, uint64_t seed);
 /* Copy states to the host as count x 6 uint32 {d, v0..v4} (test/diagnostic use). */
@@ -134,6 +142,14 @@ void crt_rng_free(crt_rng *rng);
 int crt_render_rows(const crt_scene *scene, const crt_camera *camera, crt_rng *rng, int nx,
                     int ny, int samples, int max_depth, int frame_index, int row_begin,
                     int row_count, float *d_rgb, void *stream);
+
+/* The same kernel on a strip set (see crt_rng_create_strips): multi-GPU load balancing.
+ * A contiguous band gives the ranks that own the object all the work; strips of 32 rows
+ * dealt round-robin spread it.  d_rgb holds crt_strip_rows(...)*nx*3 floats, strip after
+ * strip.  Pixels are identical to crt_render_rows on the same image rows. */
+int crt_render_strips(const crt_scene *scene, const crt_camera *camera, crt_rng *rng, int nx,
+                      int ny, int samples, int max_depth, int frame_index, int first_strip,
+                      int strip_rows, int strip_step, float *d_rgb, void *stream);
 
 /* replaces: one frame of renderListAnimation (core/render.h:159-189): allocates device
  * RNG states and a device colour buffer, renders the full image on the current device,
@@ -163,6 +179,9 @@ int crt_debug_tiled_stats(int enable, uint64_t *out24);
  * library on the calling thread, measured with HIP events on the launch stream.
  * Synchronises on that stream.  Negative on error. */
 float crt_last_kernel_ms(void);
+/* Same measurement split per kernel: ms3[0] = total, ms3[1] = binning kernel (0 for the
+ * brute-force variant), ms3[2] = shading / brute-force kernel. */
+int crt_last_kernel_times(float *ms3);
 
 /* ---- output -------------------------------------------------------------------- */
 

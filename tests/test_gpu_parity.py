@@ -164,6 +164,37 @@ def test_row_bands_equal_full_image(gpu, variant):
         assert np.array_equal(bits(np.concatenate(parts, axis=0)), bits(full)), world
 
 
+def test_round_robin_strips_equal_full_image(gpu, variant):
+    """crt_render_strips (multi-GPU load balancing): every rank's strip set, rendered on its
+    own, reproduces the full frame bit for bit, and so do the RNG states."""
+    from cudaraytracer_amd.dist import partition_strips
+    sc = scenes.displaced_sphere(10, 12)
+    nx, ny, spp = 90, 150, 2
+    scene, cam = make(sc, nx, ny)
+    (full,), full_states = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+    full_states = full_states.reshape(ny, nx, 6)
+    for world in (2, 3, 8):
+        for r in range(world):
+            strips = partition_strips(ny, world, r)
+            if not strips:
+                continue
+            rows = sum(c for _, c in strips)
+            assert rows == api.strip_rows(ny, r, 32, world)
+            st = api.CurandState.for_strips(nx, ny, r, 32, world, 0)
+            d = gpu.zeros(rows * nx * 3, dtype=gpu.float32, device="cuda")
+            api.render_strips(scene, cam, st, nx, ny, spp, r, 32, world, d, stream=gpu.cuda.current_stream())
+            gpu.cuda.synchronize()
+            got = d.cpu().numpy().reshape(rows, nx, 3)
+            ref = np.concatenate([full[y0:y0 + c] for y0, c in strips], axis=0)
+            assert np.array_equal(bits(got), bits(ref)), (world, r)
+            ref_st = np.concatenate([full_states[y0:y0 + c] for y0, c in strips], axis=0).reshape(-1, 6)
+            got_st = st.export()
+            keep = np.ones(len(ref_st), bool)
+            if r == 0:
+                keep[0] = False            # stream 0 (pixel 0): see DESIGN.md §1
+            assert np.array_equal(got_st[keep], ref_st[keep]), (world, r)
+
+
 def test_obj_path_and_png(gpu, oracle, tmp_path):
     sc = scenes.displaced_sphere(8, 10, index_base=1)
     path = scenes.write_obj(str(tmp_path / "mesh.obj"), sc)

@@ -8,13 +8,15 @@ import json
 import sys
 
 prof, kname, ksec, outp = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
-out = {}
+out, disp = {}, {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     for f in glob.glob("%s/%s/*/*_counter_collection.csv" % (prof, d)):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             out.setdefault(k, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
-out = {k: dict(v) for k, v in out.items()}
+            disp.setdefault((k, r["Counter_Name"]), set()).add(r["Dispatch_Id"])
+# per-launch averages: a counter row exists per dispatch (and per XCD/SE slice), so divide by dispatches
+out = {k: {c: v / max(1, len(disp[(k, c)])) for c, v in cs.items()} for k, cs in out.items()}
 key = [k for k in out if kname in k][0]
 r = out[key]
 fetch_b, write_b = r.get("FETCH_SIZE", 0) * 1024, r.get("WRITE_SIZE", 0) * 1024
