@@ -570,8 +570,8 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     }
     HIP_TRY(hipEventRecord(g_ev_start, stream));
     HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
-                               d_rgb, kernel_variant, kernel_variant ? &g_ws.w : nullptr, g_ws.n_cus, g_d_stats,
-                               kernel_variant ? g_ev_mid : nullptr, stream));
+                               d_rgb, kernel_variant, kernel_variant ? &g_ws.w : nullptr, g_ws.n_cus,
+                               scene->tiled_safe && cam_ok, g_d_stats, kernel_variant ? g_ev_mid : nullptr, stream));
     g_ev_has_mid = kernel_variant != 0;
     HIP_TRY(hipEventRecord(g_ev_stop, stream));
     g_ev_valid = true;
@@ -598,6 +598,24 @@ int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords =
         (void)hipFree(g_d_stats);
         g_d_stats = nullptr;
     }
+    return CRT_OK;
+}
+
+int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t* mismatches) {
+    // Exhaustive self-check of the 3-instruction reciprocal used by the kernels on bounded
+    // scenes: all floats with biased exponent in [exp_lo, exp_hi], both signs.
+    if (!mismatches || exp_lo < 0 || exp_hi > 255 || exp_lo > exp_hi) return fail(CRT_ERR_INVALID, "crt_debug_check_reciprocal: bad range");
+    if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_debug_check_reciprocal: no HIP device");
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = crt::launch_check_reciprocal((uint32_t)exp_lo, (uint32_t)exp_hi, d, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CRT_ERR_HIP, "crt_debug_check_reciprocal: %s", hipGetErrorString(e));
+    *mismatches = h;
     return CRT_OK;
 }
 

@@ -198,6 +198,11 @@ __device__ __forceinline__ V3 sky_from_unit(V3 v) {
 // wave-uniform: the record arrives through scalar loads and feeds the VALU as SGPR operands;
 // after each of the reference's rejection tests the wavefront votes and leaves as soon as no
 // lane is alive.
+#ifndef CRT_WALK_BATCH
+#define CRT_WALK_BATCH 2
+#endif
+constexpr int kWalkBatch = CRT_WALK_BATCH;
+
 struct Rec16 {
     float f[kRecFloats];
 };
@@ -211,6 +216,26 @@ __device__ __forceinline__ Rec16 load_rec(const float* __restrict__ rec, int idx
     return o;
 }
 
+// f = 1.0 / a (shapes/triangle.h:80; the double division rounded to float equals the fp32
+// IEEE quotient).  v_rcp_f32 followed by ONE Newton step is bit-identical to the IEEE
+// quotient 1.0f/a for every float with 2^-100 <= |a| <= 2^100 on gfx950 — verified
+// exhaustively (tools/rcp_exhaustive.hip, tests/test_gpu_parity.py::test_fast_reciprocal_
+// is_exact).  On this path |a| >= EPSILON = 2^-20 for every lane whose result is used and
+// |a| <= |e1||e2| <= 2^84 because the host only selects FAST for scenes whose coordinates are
+// bounded by 2^38; otherwise the compiler's IEEE sequence is used.
+template <bool FAST>
+__device__ __forceinline__ float reciprocal(float a) {
+    if (FAST) {
+        float r = __builtin_amdgcn_rcpf(a);
+        float e = __builtin_fmaf(-a, r, 1.0f);
+        return __builtin_fmaf(e, r, r);
+    }
+    return 1.0f / a;
+}
+
+// Votes are kept as 64-bit lane masks in SGPRs (v_cmp -> s_and_b64 -> s_cbranch_scc), the
+// per-lane predicate is only rebuilt for the final conditional update.
+template <bool FAST>
 __device__ __forceinline__ void exact_test(const Rec16& rc, int i, V3 d, float& closest, int& hit_idx) {
     const float nx = rc.f[0], ny = rc.f[1], nz = rc.f[2];
     const float e2x = rc.f[3], e2y = rc.f[4], e2z = rc.f[5];
@@ -221,8 +246,8 @@ __device__ __forceinline__ void exact_test(const Rec16& rc, int i, V3 d, float& 
 
     // if (dot(r.direction(), normal) < 0) return false;            triangle.h:61
     float dn = d.x * nx + d.y * ny + d.z * nz;
-    bool alive = !(dn < 0.0f);
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+    unsigned long long alive = __builtin_amdgcn_ballot_w64(!(dn < 0.0f));
+    if (alive == 0ull) return;
 
     // h = cross(r.direction(), edge2); a = dot(edge1, h);            triangle.h:71-72
     float hx = (d.y * e2z - d.z * e2y);
@@ -230,21 +255,21 @@ __device__ __forceinline__ void exact_test(const Rec16& rc, int i, V3 d, float& 
     float hz = (d.x * e2y - d.y * e2x);
     float a = e1x * hx + e1y * hy + e1z * hz;
     // if (a > -EPSILON && a < EPSILON) return false;                triangle.h:77 (backCulling is false)
-    alive = alive && !(a > -kTriEpsilon && a < kTriEpsilon);
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+    alive &= __builtin_amdgcn_ballot_w64(!(fabsf(a) < kTriEpsilon));
+    if (alive == 0ull) return;
 
-    float f = 1.0f / a;                     // f = 1.0 / a (double site, == fp32 IEEE divide), triangle.h:80
+    float f = reciprocal<FAST>(a);                                    // triangle.h:80
     float u = f * (sx * hx + sy * hy + sz * hz);                      // triangle.h:82
-    alive = alive && !(u < 0.0f || u > 1.0f);                         // triangle.h:84
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+    alive &= __builtin_amdgcn_ballot_w64(!(u < 0.0f)) & __builtin_amdgcn_ballot_w64(!(u > 1.0f));   // triangle.h:84
+    if (alive == 0ull) return;
 
     float v = f * (d.x * qx + d.y * qy + d.z * qz);                   // triangle.h:88
-    alive = alive && !(v < 0.0f || u + v > 1.0f);                     // triangle.h:89
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
+    alive &= __builtin_amdgcn_ballot_w64(!(v < 0.0f)) & __builtin_amdgcn_ballot_w64(!(u + v > 1.0f));   // triangle.h:89
+    if (alive == 0ull) return;
 
     float t = f * tq;                                                 // triangle.h:92
     // hit(...) && tmp_rec.t < closest_so_far                         hitable_list.h:84
-    if (alive && t < closest) {
+    if (__builtin_amdgcn_inverse_ballot_w64(alive) && t < closest) {
         closest = t;
         hit_idx = i;
     }
@@ -254,23 +279,38 @@ __device__ __forceinline__ void exact_test(const Rec16& rc, int i, V3 d, float& 
 // of position k.  (A manual one-ahead prefetch of the next record was measured 1.75x SLOWER:
 // SMEM returns out of order, so hipcc must drain lgkmcnt to 0 before the first use of any
 // scalar-loaded register and then shuffles the record through s_mov copies.)
-template <class IndexAt>
+template <bool FAST, class IndexAt>
 __device__ __forceinline__ void walk(const float* __restrict__ rec, int k0, int k1, IndexAt index_at,
                                      V3 d, float& closest, int& hit_idx) {
-    for (int k = k0; k < k1; ++k) {
+    // kWalkBatch records are requested together and waited for once: the scalar-load latency
+    // is paid per batch, not per triangle (it bounds the time of a heavy tile).
+    int k = k0;
+    for (; k + kWalkBatch <= k1; k += kWalkBatch) {
+        int idx[kWalkBatch];
+        Rec16 r[kWalkBatch];
+#pragma unroll
+        for (int j = 0; j < kWalkBatch; ++j) {
+            idx[j] = index_at(k + j);
+            r[j] = load_rec(rec, idx[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kWalkBatch; ++j) exact_test<FAST>(r[j], idx[j], d, closest, hit_idx);
+    }
+    for (; k < k1; ++k) {
         const int idx = index_at(k);
-        exact_test(load_rec(rec, idx), idx, d, closest, hit_idx);
+        exact_test<FAST>(load_rec(rec, idx), idx, d, closest, hit_idx);
     }
 }
 
 // Same over a survivor list in global memory: 64 indices at a time are fetched with one
 // coalesced vector load (lane j holds position base+j) and handed out with v_readlane.
+template <bool FAST>
 __device__ __forceinline__ void walk_list(const float* __restrict__ rec, const uint32_t* __restrict__ lst,
                                           int k0, int k1, int lane, V3 d, float& closest, int& hit_idx) {
     for (int base = k0; base < k1; base += 64) {
         const int n = min(64, k1 - base);
         const int mine = (lane < n) ? (int)lst[base + lane] : 0;
-        walk(rec, 0, n, [&](int k) { return __builtin_amdgcn_readlane(mine, k); }, d, closest, hit_idx);
+        walk<FAST>(rec, 0, n, [&](int k) { return __builtin_amdgcn_readlane(mine, k); }, d, closest, hit_idx);
     }
 }
 
@@ -469,6 +509,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 // ---------------------------------------------------------------- variant 0: brute force
 // One lane = one pixel; one wavefront = an 8x8 pixel tile; one 256-thread block = 16x16.
 // Every ray walks the whole list.
+template <bool FAST>
 __global__ void __launch_bounds__(256)
 render_list_kernel(RenderParams p, const float* __restrict__ rec,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state,
@@ -480,7 +521,7 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
     if (x >= p.nx || ly >= p.row_count) return;                        // render.h:109
     const int n_tris = p.n_tris;
     render_pixel(p, x, ly, shade_n, state, rgb, true, [&](V3 d2, float& closest, int& hit_idx) {
-        walk(rec, 0, n_tris, [](int k) { return k; }, d2, closest, hit_idx);
+        walk<FAST>(rec, 0, n_tris, [](int k) { return k; }, d2, closest, hit_idx);
     });
 }
 
@@ -739,8 +780,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                     if (!walk_all) walk_list_v(rec, lst, k0, k1, lane, d2, closest, hit_idx);
                     else walk_v(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
                 } else {
-                    if (!walk_all) walk_list(rec, lst, k0, k1, lane, d2, closest, hit_idx);
-                    else walk(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
+                    if (!walk_all) walk_list<true>(rec, lst, k0, k1, lane, d2, closest, hit_idx);
+                    else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
                 }
                 part_t[parity][wave][lane] = closest;
                 part_i[parity][wave][lane] = hit_idx;
@@ -788,8 +829,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                     walk_v(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
                     walk_v(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
                 } else {
-                    walk(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
-                    walk(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
+                    walk<true>(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
+                    walk<true>(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
                 }
             });
         }
@@ -853,13 +894,16 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const C
 
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
-                         const TiledWork* work, int n_cus, unsigned long long* d_stats, hipEvent_t ev_mid,
-                         hipStream_t stream) {
+                         const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
+                         hipEvent_t ev_mid, hipStream_t stream) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     if (variant == 0 || d_cls == nullptr || work == nullptr) {
         dim3 block(256);
         dim3 grid((unsigned)((p.nx + 15) / 16), (unsigned)((p.row_count + 15) / 16));
-        hipLaunchKernelGGL(render_list_kernel, grid, block, 0, stream, p, d_rec, d_shade_n, d_state, d_rgb);
+        if (fast_rcp)
+            hipLaunchKernelGGL(render_list_kernel<true>, grid, block, 0, stream, p, d_rec, d_shade_n, d_state, d_rgb);
+        else
+            hipLaunchKernelGGL(render_list_kernel<false>, grid, block, 0, stream, p, d_rec, d_shade_n, d_state, d_rgb);
         return hipGetLastError();
     }
     TiledWork w = *work;
@@ -887,6 +931,26 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     else
         hipLaunchKernelGGL(shade_tiles_kernel<true>, grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
                            d_rgb, w, d_stats);
+    return hipGetLastError();
+}
+
+// Self-check of reciprocal<true>: every float with biased exponent in [exp_lo, exp_hi], both
+// signs, against the compiler's IEEE 1.0f / a.
+__global__ void __launch_bounds__(256)
+check_reciprocal_kernel(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* __restrict__ bad) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long total = (unsigned long long)(exp_hi - exp_lo + 1) << 24;
+    unsigned long long mine = 0;
+    for (; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t bits = ((uint32_t)(i & 1) << 31) | ((exp_lo + (uint32_t)(i >> 24)) << 23) | (uint32_t)((i >> 1) & 0x7fffff);
+        const float a = __uint_as_float(bits);
+        mine += (__float_as_uint(reciprocal<true>(a)) != __float_as_uint(1.0f / a)) ? 1ull : 0ull;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+hipError_t launch_check_reciprocal(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad, hipStream_t stream) {
+    hipLaunchKernelGGL(check_reciprocal_kernel, dim3(4096), dim3(256), 0, stream, exp_lo, exp_hi, d_bad);
     return hipGetLastError();
 }
 

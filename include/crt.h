@@ -175,6 +175,13 @@ int crt_set_kernel_variant(int variant);
  * enable == 0 stops it.  Counting costs a few atomics per wavefront. */
 int crt_debug_tiled_stats(int enable, uint64_t *out24);
 
+/* Self-check: the kernels compute f = 1.0/a (shapes/triangle.h:80) as v_rcp_f32 + one Newton
+ * step when the scene is bounded (|coordinate| <= 2^38, so 2^-20 <= |a| <= 2^84 wherever f
+ * is used).  This compares that sequence with the IEEE quotient for EVERY float whose biased
+ * exponent lies in [exp_lo, exp_hi], both signs, on the current device; *mismatches must be 0
+ * for [27, 227] (2^-100 .. 2^100). */
+int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t *mismatches);
+
 /* Duration in milliseconds of the last crt_render_rows main kernel launched through this
  * library on the calling thread, measured with HIP events on the launch stream.
  * Synchronises on that stream.  Negative on error. */
