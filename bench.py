@@ -52,12 +52,12 @@ def algorithmic_bytes_brute(nx, rows, spp, n_tris):
 
 
 def algorithmic_bytes_tiled(nx, rows, spp, n_tris, regions, sum1, sum2):
-    """Tiled variant.  bin kernel: every 32x32 region streams all 64-B
+    """Tiled variant.  bin kernel: every 128x32 region streams all 64-B
     classification records once, every tile re-reads its region's survivors twice (count +
     write pass) and writes its list; shade kernel: every (tile, sample) reads the 64-B exact
     record of each of the tile's survivors, the list once per tile, plus framebuffer + RNG."""
     px = nx * rows
-    bin_b = regions * n_tris * REC_BYTES + 2 * 16 * sum1 * REC_BYTES + sum2 * 4
+    bin_b = regions * n_tris * REC_BYTES + 2 * 64 * sum1 * REC_BYTES + sum2 * 4
     shade_b = spp * sum2 * REC_BYTES + sum2 * 4 + px * 12 + px * 48
     return bin_b, shade_b
 
@@ -178,7 +178,7 @@ def main():
             kernels = {
                 "bin_tiles_kernel": {"ms": k_bin, "algorithmic_bytes": bin_b, "GB/s": bin_b / (k_bin * 1e-3) / 1e9,
                                      "note": "lane = triangle, coalesced stream of 64-B classification records, "
-                                             "once per 32x32 region (L2/MALL resident: %.1f MB)" % (n_tris * 64 / 1e6)},
+                                             "once per 128x32 region (L2/MALL resident: %.1f MB)" % (n_tris * 64 / 1e6)},
                 "shade_tiles_kernel": {"ms": k_shade, "algorithmic_bytes": shade_b,
                                        "GB/s": shade_b / (k_shade * 1e-3) / 1e9,
                                        "note": "lane = pixel, exact reference arithmetic on tile survivors; "

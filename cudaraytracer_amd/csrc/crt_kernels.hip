@@ -539,10 +539,12 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
 //   phase A2 (lane = list entry, per wave):   re-classify against the wave's own 8x8 tile.
 //   phase B  (lane = pixel):                  the reference arithmetic (exact_test) on the
 //            tile's survivors only, in ascending index order.
-constexpr int kRegion = 32;
+constexpr int kRegionW = 128;  // region = 128 x 32 pixels = 16 x 4 tiles: wide, so that strips stay 32 rows
+constexpr int kRegionH = 32;
+constexpr int kRegionTilesX = kRegionW / 8, kRegionTiles = (kRegionW / 8) * (kRegionH / 8);
 constexpr int kTiledThreads = 1024;
 constexpr int kTiledWaves = kTiledThreads / 64;
-constexpr int kK1Max = 8192;   // region list capacity (indices)
+constexpr int kK1Max = 16384;  // region list capacity (indices)
 constexpr int kHeavyMin = 64;  // tiles with more survivors than this are traced by all 16 waves together (measured optimum, 16..128 swept)
 constexpr unsigned kNoList = 0xffffffffu;   // tile_desc.y: the pool was full, walk every triangle
 
@@ -639,13 +641,13 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
     const float fnx = (float)p.nx, fny = (float)p.ny;
     const unsigned long long lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    // region = 32x32 pixels: 32 local rows (never straddles a strip: strip_rows % 32 == 0 or
+    // region = 128x32 pixels: 32 local rows (never straddles a strip: strip_rows % 32 == 0 or
     // strip_step == 1); ry* are global image rows
-    const int rx0 = blockIdx.x * kRegion;
-    const int rly0 = blockIdx.y * kRegion;
+    const int rx0 = blockIdx.x * kRegionW;
+    const int rly0 = blockIdx.y * kRegionH;
     const int ry0 = global_row(p.row_begin, p.strip_rows, p.strip_step, rly0);
-    const int rx1 = min(rx0 + kRegion, p.nx);
-    const int ry1 = ry0 + min(kRegion, p.row_count - rly0);
+    const int rx1 = min(rx0 + kRegionW, p.nx);
+    const int ry1 = ry0 + min(kRegionH, p.row_count - rly0);
 
     // ---- phase A: all classification records against the region rectangle
     TileBox rb = make_box(p.cam, (float)rx0, (float)rx1, (float)ry0, (float)ry1, fnx, fny);
@@ -678,54 +680,56 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
         atomicAdd(&stats[3], overflow1 ? 1ull : 0ull);
     }
 
-    // ---- phase A2: the wave's own 8x8 tile; pass 0 counts, pass 1 writes to the pool
-    const int tile_x = blockIdx.x * 4 + (wave & 3);
-    const int tile_y = blockIdx.y * 4 + (wave >> 2);
-    if (tile_x >= w.tiles_x || tile_y >= w.tiles_y) return;   // tile outside the image/band (no barriers below)
-    const int tile_id = tile_y * w.tiles_x + tile_x;
-    const int tx0 = tile_x * 8, ty0 = ry0 + (wave >> 2) * 8;
-    const int tx1 = min(tx0 + 8, rx1), ty1 = min(ty0 + 8, ry1);
-    TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
+    // ---- phase A2: each wave takes 4 of the region's 64 tiles; pass 0 counts, pass 1 writes to the pool
     const int src_count = overflow1 ? n_tris : cnt1;
-    int cnt2 = 0;
-    unsigned long long off = 0;
-    bool fits = true;
-    for (int pass = 0; pass < 2; ++pass) {
-        int run = 0;
-        for (int j = 0; j < src_count; j += 64) {
-            const int k = j + lane;
-            int idx = -1;
-            if (k < src_count) idx = overflow1 ? k : (int)list1[k];
-            bool s = (idx >= 0) && classify(cls, n_pad, idx, tb);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
-            if (pass == 1 && s) w.pool[off + (unsigned)(run + __builtin_popcountll(m & lanemask_lt))] = (uint32_t)idx;
-            run += __builtin_popcountll(m);
+    for (int tt = wave; tt < kRegionTiles; tt += kTiledWaves) {
+        const int tile_x = blockIdx.x * kRegionTilesX + (tt % kRegionTilesX);
+        const int tile_y = blockIdx.y * (kRegionH / 8) + (tt / kRegionTilesX);
+        if (tile_x >= w.tiles_x || tile_y >= w.tiles_y) continue;   // tile outside the image/band
+        const int tile_id = tile_y * w.tiles_x + tile_x;
+        const int tx0 = tile_x * 8, ty0 = ry0 + (tt / kRegionTilesX) * 8;
+        const int tx1 = min(tx0 + 8, rx1), ty1 = min(ty0 + 8, ry1);
+        TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
+        int cnt2 = 0;
+        unsigned long long off = 0;
+        bool fits = true;
+        for (int pass = 0; pass < 2; ++pass) {
+            int run = 0;
+            for (int j = 0; j < src_count; j += 64) {
+                const int k = j + lane;
+                int idx = -1;
+                if (k < src_count) idx = overflow1 ? k : (int)list1[k];
+                bool s = (idx >= 0) && classify(cls, n_pad, idx, tb);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
+                if (pass == 1 && s) w.pool[off + (unsigned)(run + __builtin_popcountll(m & lanemask_lt))] = (uint32_t)idx;
+                run += __builtin_popcountll(m);
+            }
+            if (pass == 0) {
+                cnt2 = run;
+                unsigned long long o = 0;
+                if (lane == 0) o = atomicAdd(&w.counters64[0], (unsigned long long)cnt2);
+                off = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(o >> 32)) << 32) |
+                      (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)o);
+                fits = off + (unsigned long long)cnt2 <= (unsigned long long)w.pool_cap;
+                if (!fits || cnt2 == 0) break;
+            }
         }
-        if (pass == 0) {
-            cnt2 = run;
-            unsigned long long o = 0;
-            if (lane == 0) o = atomicAdd(&w.counters64[0], (unsigned long long)cnt2);
-            off = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(o >> 32)) << 32) |
-                  (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)o);
-            fits = off + (unsigned long long)cnt2 <= (unsigned long long)w.pool_cap;
-            if (!fits || cnt2 == 0) break;
-        }
-    }
-    if (lane == 0) {
-        // weight class: 0 = no list (walk every triangle) or > 1024, 1 = > 256, 2 = > heavy_min, 3 = light
-        const unsigned weight = fits ? (unsigned)cnt2 : 0xffffffffu;
-        const int c = (weight > 1024u) ? 0 : (weight > 256u ? 1 : (weight > (unsigned)heavy_min ? 2 : 3));
-        w.tile_desc[tile_id] = make_uint2((unsigned)off, fits ? (unsigned)cnt2 : kNoList);
-        const unsigned pos = atomicAdd(&w.counters[kCtrQueueLen + c], 1u);
-        w.queue[(size_t)c * w.tiles_total + pos] = (uint32_t)tile_id;
-        if (stats) {
-            atomicAdd(&stats[4], 1ull);
-            atomicAdd(&stats[5], (unsigned long long)cnt2);
-            atomicMax(&stats[6], (unsigned long long)cnt2);
-            atomicAdd(&stats[7], fits ? 0ull : 1ull);
-            int bucket = 0;
-            while ((cnt2 >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt2 in [2^(b-1), 2^b)
-            atomicAdd(&stats[8 + bucket], 1ull);
+        if (lane == 0) {
+            // weight class: 0 = no list (walk every triangle) or > 1024, 1 = > 256, 2 = > heavy_min, 3 = light
+            const unsigned weight = fits ? (unsigned)cnt2 : 0xffffffffu;
+            const int c = (weight > 1024u) ? 0 : (weight > 256u ? 1 : (weight > (unsigned)heavy_min ? 2 : 3));
+            w.tile_desc[tile_id] = make_uint2((unsigned)off, fits ? (unsigned)cnt2 : kNoList);
+            const unsigned pos = atomicAdd(&w.counters[kCtrQueueLen + c], 1u);
+            w.queue[(size_t)c * w.tiles_total + pos] = (uint32_t)tile_id;
+            if (stats) {
+                atomicAdd(&stats[4], 1ull);
+                atomicAdd(&stats[5], (unsigned long long)cnt2);
+                atomicMax(&stats[6], (unsigned long long)cnt2);
+                atomicAdd(&stats[7], fits ? 0ull : 1ull);
+                int bucket = 0;
+                while ((cnt2 >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt2 in [2^(b-1), 2^b)
+                atomicAdd(&stats[8 + bucket], 1ull);
+            }
         }
     }
 }
@@ -737,13 +741,14 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
 // through LDS in slice order with the reference's strict `<`, and every wave replays the
 // same shading / RNG so the streams stay in step.  Light tiles (class 3) are then pulled
 // one per wave.
-template <bool VREC>
-__global__ void __launch_bounds__(kTiledThreads, VREC ? 4 : 8)
+template <bool VREC, int OCC>
+__global__ void __launch_bounds__(kTiledThreads, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* __restrict__ shade_n,
                    uint32_t* __restrict__ state, float* __restrict__ rgb, TiledWork w,
                    unsigned long long* __restrict__ stats) {
-    __shared__ float part_t[2][kTiledWaves][64];
-    __shared__ int part_i[2][kTiledWaves][64];
+    __shared__ float part_t[kTiledWaves][64];
+    __shared__ int part_i[kTiledWaves][64];
+    __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
 
     const int tid = threadIdx.x;
@@ -773,9 +778,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             const int xr = hx0 + (lane & 7), lyr = hly0 + (lane >> 3);
             const bool lane_valid = xr < hx1 && lyr < hly1;
             const int x = min(xr, hx1 - 1), ly = min(lyr, hly1 - 1);   // lanes off the image replay a valid pixel
-            int parity = 0;
-            render_pixel(p, x, ly, shade_n, state, rgb, lane_valid && wave == 0,
-                         [&](V3 d2, float& closest, int& hit_idx) {
+            // Master/worker: wave 0 owns the pixels' RNG streams, generates the 64 rays of each
+            // sample and shades; the other 15 waves only trace.  Two barriers per sample:
+            // B1 "rays are in LDS", B2 "partial minima are in LDS".
+            auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
                 if (VREC) {
                     if (!walk_all) walk_list_v(rec, lst, k0, k1, lane, d2, closest, hit_idx);
                     else walk_v(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
@@ -783,24 +789,38 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                     if (!walk_all) walk_list<true>(rec, lst, k0, k1, lane, d2, closest, hit_idx);
                     else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
                 }
-                part_t[parity][wave][lane] = closest;
-                part_i[parity][wave][lane] = hit_idx;
-                __syncthreads();
-                float best = FLT_MAX;
-                int best_i = -1;
+            };
+            if (wave == 0) {
+                render_pixel(p, x, ly, shade_n, state, rgb, lane_valid,
+                             [&](V3 d2, float& closest, int& hit_idx) {
+                    ray_d[0][lane] = d2.x;
+                    ray_d[1][lane] = d2.y;
+                    ray_d[2][lane] = d2.z;
+                    __syncthreads();   // B1
+                    trace_slice(d2, closest, hit_idx);
+                    __syncthreads();   // B2
 #pragma unroll
-                for (int k = 0; k < kTiledWaves; ++k) {
-                    const float tw = part_t[parity][k][lane];
-                    const int iw = part_i[parity][k][lane];
-                    if (iw >= 0 && tw < best) {      // strict <: the lower slice (lower index) keeps ties
-                        best = tw;
-                        best_i = iw;
+                    for (int k = 1; k < kTiledWaves; ++k) {
+                        const float tw = part_t[k][lane];
+                        const int iw = part_i[k][lane];
+                        if (iw >= 0 && tw < closest) {   // strict <: the lower slice (lower index) keeps ties
+                            closest = tw;
+                            hit_idx = iw;
+                        }
                     }
+                });
+            } else {
+                for (int smp = 0; smp < p.samples; ++smp) {
+                    __syncthreads();   // B1
+                    const V3 d2 = V3{ray_d[0][lane], ray_d[1][lane], ray_d[2][lane]};
+                    float closest = FLT_MAX;
+                    int hit_idx = -1;
+                    trace_slice(d2, closest, hit_idx);
+                    part_t[wave][lane] = closest;
+                    part_i[wave][lane] = hit_idx;
+                    __syncthreads();   // B2
                 }
-                closest = best;
-                hit_idx = best_i;
-                parity ^= 1;
-            });
+            }
             __syncthreads();   // partial buffers are reused by the next tile
         }
     }
@@ -916,7 +936,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     dim3 block(kTiledThreads);
-    dim3 grid_bin((unsigned)((p.nx + kRegion - 1) / kRegion), (unsigned)((p.row_count + kRegion - 1) / kRegion));
+    dim3 grid_bin((unsigned)((p.nx + kRegionW - 1) / kRegionW), (unsigned)((p.row_count + kRegionH - 1) / kRegionH));
     hipLaunchKernelGGL(bin_tiles_kernel, grid_bin, block, 0, stream, p, d_cls, n_pad, w, k1, heavy, d_stats);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -925,11 +945,16 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         if (e != hipSuccess) return e;
     }
     dim3 grid_shade((unsigned)std::max(1, std::min(n_cus * blocks_per_cu, w.tiles_total)));
-    if (variant != 3)
-        hipLaunchKernelGGL(shade_tiles_kernel<false>, grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
+    int occ = 8;
+    if (const char* e = getenv("CRT_SHADE_OCC")) occ = atoi(e);
+    if (variant == 3)
+        hipLaunchKernelGGL((shade_tiles_kernel<true, 4>), grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
+                           d_rgb, w, d_stats);
+    else if (occ == 4)
+        hipLaunchKernelGGL((shade_tiles_kernel<false, 4>), grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
                            d_rgb, w, d_stats);
     else
-        hipLaunchKernelGGL(shade_tiles_kernel<true>, grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
+        hipLaunchKernelGGL((shade_tiles_kernel<false, 8>), grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
                            d_rgb, w, d_stats);
     return hipGetLastError();
 }
