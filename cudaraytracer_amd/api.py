@@ -201,7 +201,7 @@ def last_kernel_times():
 
 def tiled_stats(enable):
     """crt_debug_tiled_stats: returns the 32 counters collected so far, then (re)starts or stops."""
-    out = (C.c_uint64 * 32)()
+    out = (C.c_uint64 * 48)()
     check(_lib.lib().crt_debug_tiled_stats(1 if enable else 0, out))
     return list(out)
 

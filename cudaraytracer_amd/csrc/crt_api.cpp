@@ -579,7 +579,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
 }
 }  // namespace
 
-int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords = 32 words
+int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords = 48 words
     // Diagnostics: per-thread device counters filled by the tiled kernel (regions, sum/max of the
     // region survivor count, region overflows, tiles, sum/max of the tile survivor count, tile
     // overflows, then a log2 histogram of the tile survivor count).  enable=1 allocates/zeroes,

@@ -98,6 +98,6 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
                          hipEvent_t ev_mid, hipStream_t stream);
 hipError_t launch_check_reciprocal(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad, hipStream_t stream);
-constexpr int kStatsWords = 32;
+constexpr int kStatsWords = 48;
 
 }  // namespace crt

@@ -649,6 +649,7 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
     const int rx1 = min(rx0 + kRegionW, p.nx);
     const int ry1 = ry0 + min(kRegionH, p.row_count - rly0);
 
+    const long long bclk0 = stats ? (long long)clock64() : 0;
     // ---- phase A: all classification records against the region rectangle
     TileBox rb = make_box(p.cam, (float)rx0, (float)rx1, (float)ry0, (float)ry1, fnx, fny);
     int cnt1 = 0;
@@ -680,6 +681,7 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
         atomicAdd(&stats[3], overflow1 ? 1ull : 0ull);
     }
 
+    const long long bclk1 = stats ? (long long)clock64() : 0;
     // ---- phase A2: each wave takes 4 of the region's 64 tiles; pass 0 counts, pass 1 writes to the pool
     const int src_count = overflow1 ? n_tris : cnt1;
     for (int tt = wave; tt < kRegionTiles; tt += kTiledWaves) {
@@ -731,6 +733,14 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
                 atomicAdd(&stats[8 + bucket], 1ull);
             }
         }
+    }
+    if (stats && lane == 0) {
+        const long long bclk2 = (long long)clock64();
+        if (wave == 0) {
+            atomicAdd(&stats[29], (unsigned long long)(bclk1 - bclk0));   // phase A, per block
+            atomicMax(&stats[30], (unsigned long long)(bclk1 - bclk0));
+        }
+        atomicMax(&stats[31], (unsigned long long)(bclk2 - bclk1));       // phase A2, slowest wave
     }
 }
 
@@ -791,14 +801,19 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                 }
             };
             if (wave == 0) {
+                long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
                 render_pixel(p, x, ly, shade_n, state, rgb, lane_valid,
                              [&](V3 d2, float& closest, int& hit_idx) {
                     ray_d[0][lane] = d2.x;
                     ray_d[1][lane] = d2.y;
                     ray_d[2][lane] = d2.z;
+                    long long tc0 = 0, tc1 = 0, tc2 = 0;
+                    if (stats) { tc0 = (long long)clock64(); tc_setup += tc0 - tc_prev; }
                     __syncthreads();   // B1
                     trace_slice(d2, closest, hit_idx);
+                    if (stats) tc1 = (long long)clock64();
                     __syncthreads();   // B2
+                    if (stats) { tc2 = (long long)clock64(); tc_trace += tc1 - tc0; tc_wait += tc2 - tc1; tc_prev = tc2; }
 #pragma unroll
                     for (int k = 1; k < kTiledWaves; ++k) {
                         const float tw = part_t[k][lane];
@@ -809,6 +824,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                         }
                     }
                 });
+                if (stats && lane == 0) {   // master-wave time split: (merge+shade+next setup), own trace, wait for the slowest slice
+                    atomicAdd(&stats[32], (unsigned long long)tc_setup);
+                    atomicAdd(&stats[33], (unsigned long long)tc_trace);
+                    atomicAdd(&stats[34], (unsigned long long)tc_wait);
+                    atomicAdd(&stats[35], 1ull);
+                    atomicAdd(&stats[36], (unsigned long long)n_src);
+                }
             } else {
                 for (int smp = 0; smp < p.samples; ++smp) {
                     __syncthreads();   // B1

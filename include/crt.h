@@ -165,7 +165,7 @@ int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
  * by vector loads instead of SGPRs by scalar loads (A/B experiment; slower).  All variants produce identical pixels.  Returns the previous value. */
 int crt_set_kernel_variant(int variant);
 
-/* Diagnostics of the tiled variant, per calling thread.  out24 (nullable, 32 words) first receives
+/* Diagnostics of the tiled variant, per calling thread.  out24 (nullable, 48 words) first receives
  * the counters accumulated since the last enable: [0] regions, [1] sum and [2] max of the
  * region survivor count, [3] region-list overflows, [4] tiles, [5] sum and [6] max of the
  * tile survivor count, [7] tile-list overflows, [8..23] histogram of the tile survivor count
