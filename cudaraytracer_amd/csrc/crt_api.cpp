@@ -88,7 +88,7 @@ int ensure_workspace(int nx, int rows) {
         ws.w.tile_desc = nullptr;
         ws.w.queue = nullptr;
         HIP_TRY(hipMalloc(&ws.w.tile_desc, tiles * sizeof(uint2)));
-        HIP_TRY(hipMalloc(&ws.w.queue, 4 * tiles * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&ws.w.queue, crt::kClasses * tiles * sizeof(uint32_t)));
         ws.tiles = tiles;
     }
     ws.w.pool_cap = (uint32_t)std::min<size_t>(ws.pool_entries, 0xfffffff0u);

@@ -85,13 +85,18 @@ struct TiledWork {
     unsigned long long* counters64;  // [0] pool cursor (entries)
     uint32_t pool_cap;               // entries
     uint2* tile_desc;                // per tile {pool offset, count | kNoList}
-    uint32_t* queue;                 // 4 weight classes x tiles_total tile ids
+    uint32_t* queue;                 // kClasses weight classes x tiles_total tile ids
     uint32_t* counters;              // kCtrQueueLen+c: queue length, kCtrCursor+c: consumer cursor
     int tiles_x, tiles_y, tiles_total;
 };
+// Weight classes of a tile (by survivor count; heaviest first = longest-processing-time-first
+// order for the persistent shading blocks): class c < kHeavyClasses holds tiles with more than
+// kClassMin[c] survivors (class 0 also: no list), the last class the light tiles.
+constexpr int kHeavyClasses = 9;
+constexpr int kClasses = kHeavyClasses + 1;
 constexpr int kCtrQueueLen = 2;      // counters[0..1] alias counters64[0]
-constexpr int kCtrCursor = 8;
-constexpr int kCtrWords = 16;
+constexpr int kCtrCursor = 16;
+constexpr int kCtrWords = 32;
 
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,

@@ -628,11 +628,16 @@ __device__ __forceinline__ bool classify(const float4* __restrict__ cls, int n_p
 // Output: for every 8x8 tile of the band its survivor list (ascending triangle indices) in
 // a global pool, a descriptor {offset, count}, and its id appended to one of four work
 // queues by weight class.
-__global__ void __launch_bounds__(kTiledThreads)
+__global__ void __launch_bounds__(kTiledThreads, 8)
 bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledWork w, int k1_cap,
                  int heavy_min, unsigned long long* __restrict__ stats) {
     __shared__ uint32_t list1[kK1Max];
     __shared__ int wcnt[kTiledWaves];
+    __shared__ TileBox tbox[kRegionTiles];
+    __shared__ unsigned tile_cnt[kRegionTiles], tile_base[kRegionTiles];
+    __shared__ int tile_ok[kRegionTiles];
+    __shared__ unsigned long long wmask[kTiledWaves][kRegionTiles];
+    __shared__ int region_fits;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -682,56 +687,102 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
     }
 
     const long long bclk1 = stats ? (long long)clock64() : 0;
-    // ---- phase A2: each wave takes 4 of the region's 64 tiles; pass 0 counts, pass 1 writes to the pool
+    // ---- phase A2, lane = region-list entry: every thread loads the record of ONE entry and
+    // classifies it against all 64 tile rectangles of the region (boxes in LDS).  Pass 0
+    // counts per tile, one atomicAdd reserves the region's pool space, pass 1 classifies again
+    // and scatters the indices tile by tile in list order.
     const int src_count = overflow1 ? n_tris : cnt1;
-    for (int tt = wave; tt < kRegionTiles; tt += kTiledWaves) {
-        const int tile_x = blockIdx.x * kRegionTilesX + (tt % kRegionTilesX);
-        const int tile_y = blockIdx.y * (kRegionH / 8) + (tt / kRegionTilesX);
-        if (tile_x >= w.tiles_x || tile_y >= w.tiles_y) continue;   // tile outside the image/band
-        const int tile_id = tile_y * w.tiles_x + tile_x;
-        const int tx0 = tile_x * 8, ty0 = ry0 + (tt / kRegionTilesX) * 8;
+    if (tid < kRegionTiles) {
+        const int tx = blockIdx.x * kRegionTilesX + (tid % kRegionTilesX);
+        const int tyl = blockIdx.y * (kRegionH / 8) + (tid / kRegionTilesX);
+        const bool valid = tx < w.tiles_x && tyl < w.tiles_y;
+        const int tx0 = tx * 8, ty0 = ry0 + (tid / kRegionTilesX) * 8;
         const int tx1 = min(tx0 + 8, rx1), ty1 = min(ty0 + 8, ry1);
-        TileBox tb = make_box(p.cam, (float)tx0, (float)tx1, (float)ty0, (float)ty1, fnx, fny);
-        int cnt2 = 0;
-        unsigned long long off = 0;
-        bool fits = true;
-        for (int pass = 0; pass < 2; ++pass) {
-            int run = 0;
-            for (int j = 0; j < src_count; j += 64) {
-                const int k = j + lane;
-                int idx = -1;
-                if (k < src_count) idx = overflow1 ? k : (int)list1[k];
-                bool s = (idx >= 0) && classify(cls, n_pad, idx, tb);
+        tbox[tid] = make_box(p.cam, (float)tx0, (float)(valid ? tx1 : tx0 + 8), (float)ty0, (float)(valid ? ty1 : ty0 + 8), fnx, fny);
+        tile_ok[tid] = valid ? 1 : 0;
+        tile_cnt[tid] = 0;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        int run[kRegionTiles / kTiledWaves] = {0, 0, 0, 0};   // pass 1: entries already written for this wave's tiles
+        for (int base = 0; base < src_count; base += kTiledThreads) {
+            const int k = base + tid;
+            const bool have = k < src_count;
+            const int idx = have ? (overflow1 ? k : (int)list1[k]) : 0;
+            const float4 p0 = cls[(size_t)0 * n_pad + idx], p1 = cls[(size_t)1 * n_pad + idx];
+            const float4 p2 = cls[(size_t)2 * n_pad + idx], p3 = cls[(size_t)3 * n_pad + idx];
+            for (int t = 0; t < kRegionTiles; ++t) {
+                const bool s = have && may_hit(p0, p1, p2, p3, tbox[t]);
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
-                if (pass == 1 && s) w.pool[off + (unsigned)(run + __builtin_popcountll(m & lanemask_lt))] = (uint32_t)idx;
-                run += __builtin_popcountll(m);
+                if (pass == 0) {
+                    if (lane == 0 && m != 0ull) atomicAdd(&tile_cnt[t], (unsigned)__builtin_popcountll(m));
+                } else if (lane == 0) {
+                    wmask[wave][t] = m;
+                }
             }
-            if (pass == 0) {
-                cnt2 = run;
-                unsigned long long o = 0;
-                if (lane == 0) o = atomicAdd(&w.counters64[0], (unsigned long long)cnt2);
-                off = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(o >> 32)) << 32) |
-                      (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)o);
-                fits = off + (unsigned long long)cnt2 <= (unsigned long long)w.pool_cap;
-                if (!fits || cnt2 == 0) break;
+            if (pass == 1) {
+                __syncthreads();
+                // scatter: this wave owns tiles wave, wave+16, wave+32, wave+48
+#pragma unroll
+                for (int q = 0; q < kRegionTiles / kTiledWaves; ++q) {
+                    const int t = wave + q * kTiledWaves;
+                    if (tile_base[t] == kNoList) continue;
+                    for (int w2 = 0; w2 < kTiledWaves; ++w2) {
+                        const unsigned long long m = wmask[w2][t];
+                        if (m == 0ull) continue;
+                        const int k2 = base + w2 * 64 + lane;
+                        if ((m >> lane) & 1ull) {
+                            const unsigned e = overflow1 ? (unsigned)k2 : list1[k2];
+                            w.pool[(size_t)tile_base[t] + (unsigned)(run[q] + __builtin_popcountll(m & lanemask_lt))] = e;
+                        }
+                        run[q] += __builtin_popcountll(m);
+                    }
+                }
+                __syncthreads();
             }
         }
-        if (lane == 0) {
-            // weight class: 0 = no list (walk every triangle) or > 1024, 1 = > 256, 2 = > heavy_min, 3 = light
-            const unsigned weight = fits ? (unsigned)cnt2 : 0xffffffffu;
-            const int c = (weight > 1024u) ? 0 : (weight > 256u ? 1 : (weight > (unsigned)heavy_min ? 2 : 3));
-            w.tile_desc[tile_id] = make_uint2((unsigned)off, fits ? (unsigned)cnt2 : kNoList);
-            const unsigned pos = atomicAdd(&w.counters[kCtrQueueLen + c], 1u);
-            w.queue[(size_t)c * w.tiles_total + pos] = (uint32_t)tile_id;
-            if (stats) {
-                atomicAdd(&stats[4], 1ull);
-                atomicAdd(&stats[5], (unsigned long long)cnt2);
-                atomicMax(&stats[6], (unsigned long long)cnt2);
-                atomicAdd(&stats[7], fits ? 0ull : 1ull);
-                int bucket = 0;
-                while ((cnt2 >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt2 in [2^(b-1), 2^b)
-                atomicAdd(&stats[8 + bucket], 1ull);
+        if (pass == 0) {
+            __syncthreads();
+            if (tid == 0) {   // reserve the region's pool space; tiles of a region are contiguous
+                unsigned total = 0;
+                for (int t = 0; t < kRegionTiles; ++t) total += tile_ok[t] ? tile_cnt[t] : 0u;
+                const unsigned long long off = atomicAdd(&w.counters64[0], (unsigned long long)total);
+                const bool fits = off + (unsigned long long)total <= (unsigned long long)w.pool_cap;
+                unsigned at = (unsigned)off;
+                for (int t = 0; t < kRegionTiles; ++t) {
+                    tile_base[t] = (fits && tile_ok[t]) ? at : kNoList;
+                    at += tile_ok[t] ? tile_cnt[t] : 0u;
+                }
+                region_fits = fits ? 1 : 0;
             }
+            __syncthreads();
+            if (tid < kRegionTiles && tile_ok[tid]) {
+                const int tx = blockIdx.x * kRegionTilesX + (tid % kRegionTilesX);
+                const int tyl = blockIdx.y * (kRegionH / 8) + (tid / kRegionTilesX);
+                const int tile_id = tyl * w.tiles_x + tx;
+                const unsigned cnt2 = tile_cnt[tid];
+                const bool fits = region_fits != 0;
+                // weight class (heaviest first); the last heavy class starts at heavy_min, below is light
+                const unsigned weight = fits ? cnt2 : 0xffffffffu;
+                const unsigned mins[kHeavyClasses] = {1024u, 768u, 512u, 384u, 256u, 192u, 128u, 96u, (unsigned)heavy_min};
+                int c = kHeavyClasses;
+#pragma unroll
+                for (int q = kHeavyClasses - 1; q >= 0; --q)
+                    if (weight > mins[q] && weight > (unsigned)heavy_min) c = q;
+                w.tile_desc[tile_id] = make_uint2(fits ? tile_base[tid] : 0u, fits ? cnt2 : kNoList);
+                const unsigned pos = atomicAdd(&w.counters[kCtrQueueLen + c], 1u);
+                w.queue[(size_t)c * w.tiles_total + pos] = (uint32_t)tile_id;
+                if (stats) {
+                    atomicAdd(&stats[4], 1ull);
+                    atomicAdd(&stats[5], (unsigned long long)cnt2);
+                    atomicMax(&stats[6], (unsigned long long)cnt2);
+                    atomicAdd(&stats[7], fits ? 0ull : 1ull);
+                    int bucket = 0;
+                    while ((cnt2 >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt2 in [2^(b-1), 2^b)
+                    atomicAdd(&stats[8 + bucket], 1ull);
+                }
+            }
+            if (region_fits == 0) break;   // block-uniform: nothing to write
         }
     }
     if (stats && lane == 0) {
@@ -767,7 +818,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
     const int n_tris = p.n_tris;
     const long long clk0 = stats ? (long long)clock64() : 0;
 
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < kHeavyClasses; ++c) {
         const unsigned n_items = w.counters[kCtrQueueLen + c];
         while (true) {
             if (tid == 0) s_item = atomicAdd(&w.counters[kCtrCursor + c], 1u);
@@ -849,13 +900,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
     const long long clk1 = stats ? (long long)clock64() : 0;
 
     // ---- light tiles: one wave per tile, lane = pixel
-    const unsigned n_light = w.counters[kCtrQueueLen + 3];
+    const unsigned n_light = w.counters[kCtrQueueLen + kHeavyClasses];
     while (true) {
         unsigned item = 0;
-        if (lane == 0) item = atomicAdd(&w.counters[kCtrCursor + 3], 1u);
+        if (lane == 0) item = atomicAdd(&w.counters[kCtrCursor + kHeavyClasses], 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_light) break;
-        const int tile_id = __builtin_amdgcn_readfirstlane((int)w.queue[(size_t)3 * w.tiles_total + item]);
+        const int tile_id = __builtin_amdgcn_readfirstlane((int)w.queue[(size_t)kHeavyClasses * w.tiles_total + item]);
         const uint2 desc = w.tile_desc[tile_id];
         const int cnt = __builtin_amdgcn_readfirstlane((int)desc.y);
         const uint32_t* __restrict__ lst = w.pool + __builtin_amdgcn_readfirstlane(desc.x);
