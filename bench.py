@@ -192,6 +192,16 @@ def main():
             alg, k_ms, dom = algorithmic_bytes_brute(NX, br.row_count, args.spp, n_tris), k_tot, "render_list_kernel"
             kernels, survivors = {"render_list_kernel": {"ms": k_tot, "algorithmic_bytes": alg}}, None
         achieved = alg / (k_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this very
+        # command (tools/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r1_tiled", "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin"))
+        if tiled and world == 1 and args.spp == SPP and os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc))["derived"]["hbm_traffic_bytes_corrected"]
+                traffic_src = os.path.relpath(pmc, ROOT)
+            except Exception:
+                traffic = None
         out = {
             "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -207,7 +217,7 @@ def main():
             "ray_triangle_pairs_per_s": value * 1e6 * n_tris,
             "kernel_ms": k_tot,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "algorithmic_bytes_per_launch": alg},
             "kernels": kernels,
             "survivors": survivors,
