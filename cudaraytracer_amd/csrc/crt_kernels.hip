@@ -208,8 +208,8 @@ struct Rec16 {
 };
 
 // Wave-uniform address -> one s_load_dwordx16 into SGPRs.
-__device__ __forceinline__ Rec16 load_rec(const float* __restrict__ rec, int idx) {
-    const float* __restrict__ r = rec + (size_t)idx * kRecFloats;
+__device__ __forceinline__ Rec16 load_rec(const float* __restrict__ rec, int idx_raw) {
+    const float* __restrict__ r = rec + (size_t)(idx_raw & 0x7fffffff) * kRecFloats;
     Rec16 o;
 #pragma unroll
     for (int k = 0; k < kRecFloats; ++k) o.f[k] = r[k];
@@ -236,7 +236,8 @@ __device__ __forceinline__ float reciprocal(float a) {
 // Votes are kept as 64-bit lane masks in SGPRs (v_cmp -> s_and_b64 -> s_cbranch_scc), the
 // per-lane predicate is only rebuilt for the final conditional update.
 template <bool FAST>
-__device__ __forceinline__ void exact_test(const Rec16& rc, int i, V3 d, float& closest, int& hit_idx) {
+__device__ __forceinline__ void exact_test(const Rec16& rc, int i_raw, V3 d, float& closest, int& hit_idx) {
+    const int i = i_raw & 0x7fffffff;                 // bit 31 (wave-uniform): the binning proved dn >= 0 for the whole tile
     const float nx = rc.f[0], ny = rc.f[1], nz = rc.f[2];
     const float e2x = rc.f[3], e2y = rc.f[4], e2z = rc.f[5];
     const float e1x = rc.f[6], e1y = rc.f[7], e1z = rc.f[8];
@@ -245,9 +246,12 @@ __device__ __forceinline__ void exact_test(const Rec16& rc, int i, V3 d, float& 
     const float tq = rc.f[15];
 
     // if (dot(r.direction(), normal) < 0) return false;            triangle.h:61
-    float dn = d.x * nx + d.y * ny + d.z * nz;
-    unsigned long long alive = __builtin_amdgcn_ballot_w64(!(dn < 0.0f));
-    if (alive == 0ull) return;
+    unsigned long long alive = __builtin_amdgcn_ballot_w64(true);
+    if (i_raw >= 0) {
+        float dn = d.x * nx + d.y * ny + d.z * nz;
+        alive = __builtin_amdgcn_ballot_w64(!(dn < 0.0f));
+        if (alive == 0ull) return;
+    }
 
     // h = cross(r.direction(), edge2); a = dot(edge1, h);            triangle.h:71-72
     float hx = (d.y * e2z - d.z * e2y);
@@ -293,12 +297,21 @@ __device__ __forceinline__ void walk(const float* __restrict__ rec, int k0, int 
             idx[j] = index_at(k + j);
             r[j] = load_rec(rec, idx[j]);
         }
+        // Both records are consumed here, so hipcc issues the scalar loads back to back and
+        // waits once; left alone it sinks every piece of a record below the vote that first
+        // needs it (up to three dependent scalar round trips per triangle).
+        if (kWalkBatch == 2)
+            asm volatile("" ::"s"(r[0].f[0]), "s"(r[0].f[2]), "s"(r[0].f[3]), "s"(r[0].f[10]), "s"(r[0].f[11]), "s"(r[0].f[14]),
+                         "s"(r[0].f[15]), "s"(r[1].f[0]), "s"(r[1].f[2]), "s"(r[1].f[3]), "s"(r[1].f[10]), "s"(r[1].f[11]),
+                         "s"(r[1].f[14]), "s"(r[1].f[15]));
 #pragma unroll
         for (int j = 0; j < kWalkBatch; ++j) exact_test<FAST>(r[j], idx[j], d, closest, hit_idx);
     }
     for (; k < k1; ++k) {
         const int idx = index_at(k);
-        exact_test<FAST>(load_rec(rec, idx), idx, d, closest, hit_idx);
+        const Rec16 r1 = load_rec(rec, idx);
+        asm volatile("" ::"s"(r1.f[0]), "s"(r1.f[2]), "s"(r1.f[3]), "s"(r1.f[10]), "s"(r1.f[11]), "s"(r1.f[14]), "s"(r1.f[15]));
+        exact_test<FAST>(r1, idx, d, closest, hit_idx);
     }
 }
 
@@ -324,7 +337,7 @@ struct RecV {
 };
 
 __device__ __forceinline__ RecV load_rec_v(const float* __restrict__ rec, int idx_uniform) {
-    int iv = idx_uniform;
+    int iv = idx_uniform & 0x7fffffff;
     asm volatile("" : "+v"(iv));   // opaque VGPR: keeps hipcc from turning this into scalar loads
     const char* base = reinterpret_cast<const char*>(rec);
     const float4* r = reinterpret_cast<const float4*>(base + (size_t)((unsigned)iv * (unsigned)(kRecFloats * 4)));
@@ -336,7 +349,8 @@ __device__ __forceinline__ RecV load_rec_v(const float* __restrict__ rec, int id
     return o;
 }
 
-__device__ __forceinline__ void exact_test_v(const RecV& rc, int i, V3 d, float& closest, int& hit_idx) {
+__device__ __forceinline__ void exact_test_v(const RecV& rc, int i_raw, V3 d, float& closest, int& hit_idx) {
+    const int i = i_raw & 0x7fffffff;
     const float nx = rc.a.x, ny = rc.a.y, nz = rc.a.z;
     const float e2x = rc.a.w, e2y = rc.b.x, e2z = rc.b.y;
     const float e1x = rc.b.z, e1y = rc.b.w, e1z = rc.c.x;
@@ -544,9 +558,10 @@ constexpr int kRegionH = 32;
 constexpr int kRegionTilesX = kRegionW / 8, kRegionTiles = (kRegionW / 8) * (kRegionH / 8);
 constexpr int kTiledThreads = 1024;
 constexpr int kTiledWaves = kTiledThreads / 64;
-constexpr int kK1Max = 16384;  // region list capacity (indices)
+constexpr int kK1Max = 14336;  // region list capacity (indices); sized so that two blocks fit the 160 KB LDS
 constexpr int kHeavyMin = 64;  // tiles with more survivors than this are traced by all 16 waves together (measured optimum, 16..128 swept)
 constexpr unsigned kNoList = 0xffffffffu;   // tile_desc.y: the pool was full, walk every triangle
+constexpr unsigned kCullSureBit = 0x80000000u;   // pool entry flag: the cull test cannot reject in this tile
 
 struct TileBox {
     float uc, hu, vc, hv;   // centre / half extent of the rectangle in (u,v)
@@ -590,7 +605,10 @@ __device__ __forceinline__ TileBox make_box(const CameraPOD& c, float x_lo, floa
 
 // true = some ray of the rectangle may pass Triangle::collision_detection for this triangle
 // (NaN anywhere -> true).  p0..p3 are the four planes of the classification record.
-__device__ __forceinline__ bool may_hit(float4 p0, float4 p1, float4 p2, float4 p3, const TileBox& b) {
+// *cull_sure (optional): every ray of the rectangle certainly has dn >= 0, i.e. the reference's
+// first test `dot(d, normal) < 0` cannot reject — the shading kernel then skips it.
+__device__ __forceinline__ bool may_hit(float4 p0, float4 p1, float4 p2, float4 p3, const TileBox& b,
+                                        bool* cull_sure = nullptr) {
     // centre value and radius of each form over the rectangle
     float c_dn = __builtin_fmaf(b.vc, p0.z, __builtin_fmaf(b.uc, p0.y, p0.x));
     float r_dn = __builtin_fmaf(b.hv, fabsf(p0.z), b.hu * fabsf(p0.y));
@@ -611,6 +629,7 @@ __device__ __forceinline__ bool may_hit(float4 p0, float4 p1, float4 p2, float4 
     r_dn = r_dn * 1.0001f; r_a = r_a * 1.0001f; r_su = r_su * 1.0001f; r_dq = r_dq * 1.0001f; r_w = r_w * 1.0001f;
 
     bool cull_ok = !(c_dn + r_dn < -S_dn);                 // some ray may have dn >= 0
+    if (cull_sure) *cull_sure = (c_dn - r_dn > S_dn);      // dn_float >= lambda*(c-r) - kappa*M > 0 for every ray
     bool pos = !(c_a + r_a < -S_a) && !(c_su + r_su < -S_su) && !(c_dq + r_dq < -S_dq) && !(c_w + r_w < -S_w);
     bool neg = !(c_a - r_a > S_a) && !(c_su - r_su > S_su) && !(c_dq - r_dq > S_dq) && !(c_w - r_w > S_w);
     return cull_ok && (pos || neg);
@@ -636,7 +655,7 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
     __shared__ TileBox tbox[kRegionTiles];
     __shared__ unsigned tile_cnt[kRegionTiles], tile_base[kRegionTiles];
     __shared__ int tile_ok[kRegionTiles];
-    __shared__ unsigned long long wmask[kTiledWaves][kRegionTiles];
+    __shared__ unsigned long long wmask[kTiledWaves][kRegionTiles], wsure[kTiledWaves][kRegionTiles];
     __shared__ int region_fits;
 
     const int tid = threadIdx.x;
@@ -712,12 +731,17 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
             const float4 p0 = cls[(size_t)0 * n_pad + idx], p1 = cls[(size_t)1 * n_pad + idx];
             const float4 p2 = cls[(size_t)2 * n_pad + idx], p3 = cls[(size_t)3 * n_pad + idx];
             for (int t = 0; t < kRegionTiles; ++t) {
-                const bool s = have && may_hit(p0, p1, p2, p3, tbox[t]);
+                bool sure = false;
+                const bool s = have && may_hit(p0, p1, p2, p3, tbox[t], &sure);
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
                 if (pass == 0) {
                     if (lane == 0 && m != 0ull) atomicAdd(&tile_cnt[t], (unsigned)__builtin_popcountll(m));
-                } else if (lane == 0) {
-                    wmask[wave][t] = m;
+                } else {
+                    const unsigned long long ms = __builtin_amdgcn_ballot_w64(s && sure);
+                    if (lane == 0) {
+                        wmask[wave][t] = m;
+                        wsure[wave][t] = ms;
+                    }
                 }
             }
             if (pass == 1) {
@@ -730,9 +754,10 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
                     for (int w2 = 0; w2 < kTiledWaves; ++w2) {
                         const unsigned long long m = wmask[w2][t];
                         if (m == 0ull) continue;
+                        const unsigned long long ms = wsure[w2][t];
                         const int k2 = base + w2 * 64 + lane;
                         if ((m >> lane) & 1ull) {
-                            const unsigned e = overflow1 ? (unsigned)k2 : list1[k2];
+                            const unsigned e = (overflow1 ? (unsigned)k2 : list1[k2]) | (((ms >> lane) & 1ull) ? kCullSureBit : 0u);
                             w.pool[(size_t)tile_base[t] + (unsigned)(run[q] + __builtin_popcountll(m & lanemask_lt))] = e;
                         }
                         run[q] += __builtin_popcountll(m);
@@ -802,13 +827,13 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
 // through LDS in slice order with the reference's strict `<`, and every wave replays the
 // same shading / RNG so the streams stay in step.  Light tiles (class 3) are then pulled
 // one per wave.
-template <bool VREC, int OCC>
-__global__ void __launch_bounds__(kTiledThreads, OCC)
+template <bool VREC, int OCC, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* __restrict__ shade_n,
                    uint32_t* __restrict__ state, float* __restrict__ rgb, TiledWork w,
-                   unsigned long long* __restrict__ stats) {
-    __shared__ float part_t[kTiledWaves][64];
-    __shared__ int part_i[kTiledWaves][64];
+                   unsigned long long* __restrict__ stats, int dbg_repeat) {
+    __shared__ float part_t[WAVES][64];
+    __shared__ int part_i[WAVES][64];
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
 
@@ -831,7 +856,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             const bool walk_all = desc.y == kNoList;
             const int n_src = walk_all ? n_tris : (int)desc.y;
             const uint32_t* __restrict__ lst = w.pool + desc.x;
-            const int per = (n_src + kTiledWaves - 1) / kTiledWaves;
+            const int per = (n_src + WAVES - 1) / WAVES;
             const int k0 = min(n_src, wave * per), k1 = min(n_src, k0 + per);
             // local rows of the tile (tiles are 8 local rows; they never straddle a strip)
             const int hx0 = (tile_id % w.tiles_x) * 8, hly0 = (tile_id / w.tiles_x) * 8;
@@ -843,6 +868,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             // sample and shades; the other 15 waves only trace.  Two barriers per sample:
             // B1 "rays are in LDS", B2 "partial minima are in LDS".
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
+              for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (VREC) {
                     if (!walk_all) walk_list_v(rec, lst, k0, k1, lane, d2, closest, hit_idx);
                     else walk_v(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
@@ -850,6 +876,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                     if (!walk_all) walk_list<true>(rec, lst, k0, k1, lane, d2, closest, hit_idx);
                     else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
                 }
+              }
             };
             if (wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
@@ -866,7 +893,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                     __syncthreads();   // B2
                     if (stats) { tc2 = (long long)clock64(); tc_trace += tc1 - tc0; tc_wait += tc2 - tc1; tc_prev = tc2; }
 #pragma unroll
-                    for (int k = 1; k < kTiledWaves; ++k) {
+                    for (int k = 1; k < WAVES; ++k) {
                         const float tw = part_t[k][lane];
                         const int iw = part_i[k][lane];
                         if (iw >= 0 && tw < closest) {   // strict <: the lower slice (lower index) keeps ties
@@ -918,6 +945,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
         if (x < p.nx && ly < p.row_count) {
             render_pixel(p, x, ly, shade_n, state, rgb, true,
                          [&](V3 d2, float& closest, int& hit_idx) {
+              for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (VREC) {
                     walk_v(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
                     walk_v(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
@@ -925,6 +953,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                     walk<true>(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
                     walk<true>(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
                 }
+              }
             });
         }
     }
@@ -1018,17 +1047,33 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         if (e != hipSuccess) return e;
     }
     dim3 grid_shade((unsigned)std::max(1, std::min(n_cus * blocks_per_cu, w.tiles_total)));
-    int occ = 8;
+    // Waves that share a heavy tile: 8 when the launch has plenty of tiles per CU (throughput),
+    // 16 when it is small (a rank of a multi-GPU split): then the longest tile bounds the time.
+    int occ = 8, dbg_repeat = 1, group = (w.tiles_total >= n_cus * 96) ? 8 : 16;
     if (const char* e = getenv("CRT_SHADE_OCC")) occ = atoi(e);
-    if (variant == 3)
-        hipLaunchKernelGGL((shade_tiles_kernel<true, 4>), grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
-                           d_rgb, w, d_stats);
-    else if (occ == 4)
-        hipLaunchKernelGGL((shade_tiles_kernel<false, 4>), grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
-                           d_rgb, w, d_stats);
-    else
-        hipLaunchKernelGGL((shade_tiles_kernel<false, 8>), grid_shade, block, 0, stream, p, d_rec, d_shade_n, d_state,
-                           d_rgb, w, d_stats);
+    if (const char* e = getenv("CRT_SHADE_GROUP")) group = atoi(e);              // waves that share a heavy tile
+    if (const char* e = getenv("CRT_DEBUG_WALK_REPEAT")) dbg_repeat = atoi(e);   // timing experiments only
+    if (variant == 3) {
+        hipLaunchKernelGGL((shade_tiles_kernel<true, 4, 16>), grid_shade, dim3(1024), 0, stream, p, d_rec, d_shade_n,
+                           d_state, d_rgb, w, d_stats, dbg_repeat);
+    } else if (group == 8) {
+        dim3 g8((unsigned)std::max(1, std::min(n_cus * blocks_per_cu * 2, w.tiles_total)));
+        if (occ == 4)
+            hipLaunchKernelGGL((shade_tiles_kernel<false, 4, 8>), g8, dim3(512), 0, stream, p, d_rec, d_shade_n, d_state,
+                               d_rgb, w, d_stats, dbg_repeat);
+        else if (occ == 6)
+            hipLaunchKernelGGL((shade_tiles_kernel<false, 6, 8>), g8, dim3(512), 0, stream, p, d_rec, d_shade_n, d_state,
+                               d_rgb, w, d_stats, dbg_repeat);
+        else
+            hipLaunchKernelGGL((shade_tiles_kernel<false, 8, 8>), g8, dim3(512), 0, stream, p, d_rec, d_shade_n, d_state,
+                               d_rgb, w, d_stats, dbg_repeat);
+    } else if (occ == 4) {
+        hipLaunchKernelGGL((shade_tiles_kernel<false, 4, 16>), grid_shade, dim3(1024), 0, stream, p, d_rec, d_shade_n,
+                           d_state, d_rgb, w, d_stats, dbg_repeat);
+    } else {
+        hipLaunchKernelGGL((shade_tiles_kernel<false, 8, 16>), grid_shade, dim3(1024), 0, stream, p, d_rec, d_shade_n,
+                           d_state, d_rgb, w, d_stats, dbg_repeat);
+    }
     return hipGetLastError();
 }
 
