@@ -653,6 +653,7 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
     __shared__ uint32_t list1[kK1Max];
     __shared__ int wcnt[kTiledWaves];
     __shared__ TileBox tbox[kRegionTiles];
+    __shared__ float grid_uc[kRegionTilesX], grid_vc[kRegionH / 8];
     __shared__ unsigned tile_cnt[kRegionTiles], tile_base[kRegionTiles];
     __shared__ int tile_ok[kRegionTiles];
     __shared__ unsigned long long wmask[kTiledWaves][kRegionTiles], wsure[kTiledWaves][kRegionTiles];
@@ -722,6 +723,14 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
         tile_cnt[tid] = 0;
     }
     __syncthreads();
+    if (tid < kRegionTilesX) grid_uc[tid] = tbox[tid].uc;
+    if (tid < kRegionH / 8) grid_vc[tid] = tbox[tid * kRegionTilesX].vc;
+    float grid_hu = 0.0f, grid_hv = 0.0f;
+    for (int t = 0; t < kRegionTiles; ++t) {
+        grid_hu = fmaxf(grid_hu, tbox[t].hu);
+        grid_hv = fmaxf(grid_hv, tbox[t].hv);
+    }
+    __syncthreads();
     for (int pass = 0; pass < 2; ++pass) {
         int run[kRegionTiles / kTiledWaves] = {0, 0, 0, 0};   // pass 1: entries already written for this wave's tiles
         for (int base = 0; base < src_count; base += kTiledThreads) {
@@ -730,17 +739,42 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
             const int idx = have ? (overflow1 ? k : (int)list1[k]) : 0;
             const float4 p0 = cls[(size_t)0 * n_pad + idx], p1 = cls[(size_t)1 * n_pad + idx];
             const float4 p2 = cls[(size_t)2 * n_pad + idx], p3 = cls[(size_t)3 * n_pad + idx];
-            for (int t = 0; t < kRegionTiles; ++t) {
-                bool sure = false;
-                const bool s = have && may_hit(p0, p1, p2, p3, tbox[t], &sure);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
-                if (pass == 0) {
-                    if (lane == 0 && m != 0ull) atomicAdd(&tile_cnt[t], (unsigned)__builtin_popcountll(m));
-                } else {
-                    const unsigned long long ms = __builtin_amdgcn_ballot_w64(s && sure);
-                    if (lane == 0) {
-                        wmask[wave][t] = m;
-                        wsure[wave][t] = ms;
+            // The 64 tile rectangles form a regular 16 x 4 grid, so the centre value of a form
+            // is rowpart[row] + uc[col] * B: one FMA per form and tile.  Radii use the largest
+            // tile half-extents and the slack factor of the whole region (both >= the per-tile
+            // values of make_box/may_hit, so this test keeps at least what may_hit keeps).
+            const float Aw = p1.x - p2.x - p3.x, Bw = p1.y - p2.y - p3.y, Cw = p1.z - p2.z - p3.z;
+            const float q_dn = (__builtin_fmaf(grid_hv, fabsf(p0.z), grid_hu * fabsf(p0.y)) * 1.0001f) + rb.K * p0.w;
+            const float q_a = (__builtin_fmaf(grid_hv, fabsf(p1.z), grid_hu * fabsf(p1.y)) * 1.0001f) + rb.K * p1.w;
+            const float q_su = (__builtin_fmaf(grid_hv, fabsf(p2.z), grid_hu * fabsf(p2.y)) * 1.0001f) + rb.K * p2.w;
+            const float q_dq = (__builtin_fmaf(grid_hv, fabsf(p3.z), grid_hu * fabsf(p3.y)) * 1.0001f) + rb.K * p3.w;
+            const float q_w = (__builtin_fmaf(grid_hv, fabsf(Cw), grid_hu * fabsf(Bw)) * 1.0001f) +
+                              rb.K * (p2.w + p3.w + 1.25f * p1.w);
+            // sure: c_dn - r_dn > S_dn with the same r, S  <=>  c_dn > q_dn
+            for (int row = 0; row < kRegionH / 8; ++row) {
+                const float vc = grid_vc[row];
+                const float r_dn = __builtin_fmaf(vc, p0.z, p0.x), r_a = __builtin_fmaf(vc, p1.z, p1.x);
+                const float r_su = __builtin_fmaf(vc, p2.z, p2.x), r_dq = __builtin_fmaf(vc, p3.z, p3.x);
+                const float r_w = __builtin_fmaf(vc, Cw, Aw);
+                for (int col = 0; col < kRegionTilesX; ++col) {
+                    const int t = row * kRegionTilesX + col;
+                    const float uc = grid_uc[col];
+                    const float c_dn = __builtin_fmaf(uc, p0.y, r_dn), c_a = __builtin_fmaf(uc, p1.y, r_a);
+                    const float c_su = __builtin_fmaf(uc, p2.y, r_su), c_dq = __builtin_fmaf(uc, p3.y, r_dq);
+                    const float c_w = __builtin_fmaf(uc, Bw, r_w);
+                    const bool cull_ok = !(c_dn < -q_dn);
+                    const bool pos = !(c_a < -q_a) && !(c_su < -q_su) && !(c_dq < -q_dq) && !(c_w < -q_w);
+                    const bool neg = !(c_a > q_a) && !(c_su > q_su) && !(c_dq > q_dq) && !(c_w > q_w);
+                    const bool s = have && cull_ok && (pos || neg);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
+                    if (pass == 0) {
+                        if (lane == 0 && m != 0ull) atomicAdd(&tile_cnt[t], (unsigned)__builtin_popcountll(m));
+                    } else {
+                        const unsigned long long ms = __builtin_amdgcn_ballot_w64(s && (c_dn > q_dn));
+                        if (lane == 0) {
+                            wmask[wave][t] = m;
+                            wsure[wave][t] = ms;
+                        }
                     }
                 }
             }
