@@ -113,11 +113,17 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no HIP device — the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal hook (tests only): CRT_BENCH_SHARE_GPU=1 lets several ranks share the one GPU of a
+    # test box over gloo; the driver's runs use one GPU per rank over RCCL ("nccl").
+    share = os.environ.get("CRT_BENCH_SHARE_GPU") == "1"
+    dev = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     if not os.path.exists(_lib.library_path()):
         if local_rank == 0:
@@ -155,7 +161,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (world > 1 and share) else "cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

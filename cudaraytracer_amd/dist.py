@@ -41,6 +41,8 @@ def partition_strips(ny, world_size, rank, strip_rows=STRIP_ROWS):
 
 
 def _gather_padded(piece, max_elems, rank, world_size, group):
+    if piece.is_cuda and dist.get_backend(group) == "gloo":
+        piece = piece.cpu()          # rehearsal on a shared GPU: gloo has no device gather
     padded = piece.new_zeros(max_elems)
     padded[: piece.numel()] = piece.reshape(-1)
     if rank == 0:

@@ -91,6 +91,16 @@ def test_rgba8_and_png_match_oracle(crt_built, oracle, golden_dir, tmp_path):
     assert np.array_equal(decode_png(path), oracle.to_rgba8(rgb))
 
 
+def test_strip_rows_matches_partition(crt_built):
+    from cudaraytracer_amd.dist import partition_strips
+    for ny, world in [(1080, 8), (2160, 8), (75, 2), (33, 3), (64, 2)]:
+        for r in range(world):
+            strips = partition_strips(ny, world, r)
+            want = sum(c for _, c in strips)
+            got = crt_built.crt_strip_rows(ny, r, 32, world)
+            assert got == want, (ny, world, r)
+
+
 def test_compute_entry_points_fail_loudly_without_device(crt_built):
     if crt_built.crt_device_count() > 0:
         pytest.skip("a HIP device is present")
