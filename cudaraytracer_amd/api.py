@@ -206,6 +206,13 @@ def tiled_stats(enable):
     return list(out)
 
 
+def audit_tiles(scene, camera, nx, ny, samples, seed=0):
+    """crt_debug_audit_tiles: (passing pairs, pairs missing from a tile list, cull-sure violations, offender)."""
+    out = (C.c_uint64 * 4)()
+    check(_lib.lib().crt_debug_audit_tiles(scene.handle, C.byref(camera.c), nx, ny, samples, int(seed), out))
+    return tuple(out)
+
+
 def set_kernel_variant(v):
     return _lib.lib().crt_set_kernel_variant(int(v))
 

@@ -579,6 +579,45 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
 }
 }  // namespace
 
+int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int nx, int ny, int samples,
+                          uint64_t seed, uint64_t* out4) {
+    // Brute-force audit of the binning on the current device (full image): see audit_tiles_kernel.
+    if (!scene || !camera || !out4 || nx <= 0 || ny <= 0 || samples < 0)
+        return fail(CRT_ERR_INVALID, "crt_debug_audit_tiles: bad argument");
+    if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_debug_audit_tiles: no HIP device");
+    if (!scene->tiled_safe || scene->n_tris <= 0)
+        return fail(CRT_ERR_UNSUPPORTED, "crt_debug_audit_tiles: the scene is not eligible for the tiled kernels");
+    crt_rng* rng = crt_rng_create(0, (int64_t)nx * ny, seed);
+    if (!rng) return CRT_ERR_HIP;
+    crt::RenderParams p;
+    memcpy(p.cam.llc, camera->lower_left_corner, 12);
+    memcpy(p.cam.horizontal, camera->horizontal, 12);
+    memcpy(p.cam.vertical, camera->vertical, 12);
+    memcpy(p.cam.origin, camera->origin, 12);
+    memcpy(p.albedo, scene->albedo, 12);
+    p.nx = nx; p.ny = ny; p.samples = samples;
+    p.row_begin = 0; p.row_count = ny;
+    p.strip_rows = 32; p.strip_step = 1;
+    p.n_tris = scene->n_tris;
+    p.rng_count = (long long)nx * ny;
+    unsigned long long* d = nullptr;
+    int rc = ensure_workspace(nx, ny);
+    hipError_t e = (rc == CRT_OK) ? hipMalloc(&d, 4 * sizeof(unsigned long long)) : hipErrorUnknown;
+    if (e == hipSuccess) e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, scene->d_rec, nullptr);
+    if (e == hipSuccess) e = crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p.cam, scene->d_cls, nullptr);
+    if (e == hipSuccess) e = crt::launch_audit(p, scene->d_rec, scene->d_cls, scene->n_pad, rng->d_state, &g_ws.w, d, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    if (d) (void)hipFree(d);
+    crt_rng_free(rng);
+    if (rc != CRT_OK) return rc;
+    if (e != hipSuccess) return fail(CRT_ERR_HIP, "crt_debug_audit_tiles: %s", hipGetErrorString(e));
+    for (int k = 0; k < 4; ++k) out4[k] = h[k];
+    return CRT_OK;
+}
+
 int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords = 48 words
     // Diagnostics: per-thread device counters filled by the tiled kernel (regions, sum/max of the
     // region survivor count, region overflows, tiles, sum/max of the tile survivor count, tile

@@ -102,6 +102,9 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
                          hipEvent_t ev_mid, hipStream_t stream);
+hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
+                        const uint32_t* d_state, const TiledWork* work, unsigned long long* d_counters,
+                        hipStream_t stream);
 hipError_t launch_check_reciprocal(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad, hipStream_t stream);
 constexpr int kStatsWords = 48;
 

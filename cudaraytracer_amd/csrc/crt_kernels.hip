@@ -1111,6 +1111,89 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     return hipGetLastError();
 }
 
+// Audit of the binning (diagnostics/tests): brute force over ALL triangles for the rays of every
+// 8x8 tile; every (ray, triangle) pair that passes Triangle::collision_detection — closest or
+// not — must find its triangle in the tile's survivor list, and a "cull-sure" entry must never
+// see dn < 0.  counters: [0] passing pairs, [1] pairs missing from the list, [2] cull-sure
+// violations, [3] first offender (tile << 32 | triangle).
+__global__ void __launch_bounds__(256)
+audit_tiles_kernel(RenderParams p, const float* __restrict__ rec, const uint32_t* __restrict__ state,
+                   TiledWork w, unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tile_x = blockIdx.x * 2 + (wave & 1), tile_y = blockIdx.y * 2 + (wave >> 1);
+    if (tile_x >= w.tiles_x || tile_y >= w.tiles_y) return;
+    const int tile_id = tile_y * w.tiles_x + tile_x;
+    const int xr = tile_x * 8 + (lane & 7), lyr = tile_y * 8 + (lane >> 3);
+    const bool valid = xr < p.nx && lyr < p.row_count;
+    const int x = valid ? xr : tile_x * 8, ly = valid ? lyr : tile_y * 8;   // off-image lanes replay pixel 0
+    const int y = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
+    const uint2 desc = w.tile_desc[tile_id];
+    if (desc.y == kNoList) return;                    // pool was full: the tile walks every triangle anyway
+    const uint32_t* __restrict__ lst = w.pool + desc.x;
+    const int cnt = (int)desc.y;
+
+    const long long si = (long long)ly * p.nx + x, stride = p.rng_count;
+    Xorwow rs;
+    rs.d = state[0 * stride + si]; rs.v0 = state[1 * stride + si]; rs.v1 = state[2 * stride + si];
+    rs.v2 = state[3 * stride + si]; rs.v3 = state[4 * stride + si]; rs.v4 = state[5 * stride + si];
+    const float fnx = (float)p.nx, fny = (float)p.ny;
+    unsigned long long n_pass = 0, n_miss = 0, n_cull = 0;
+    for (int smp = 0; smp < p.samples; ++smp) {
+        // any jitter inside the pixel is a legitimate ray of the tile; the extreme corners are
+        // included every fourth sample to stress the rectangle bounds
+        float ju = xw_uniform(rs), jv = xw_uniform(rs);
+        if ((smp & 3) == 3) { ju = (smp & 4) ? 1.0f : 1.1641532e-10f; jv = (smp & 8) ? 1.0f : 1.1641532e-10f; }
+        const float u = ((float)x + ju) / fnx, v = ((float)y + jv) / fny;
+        const V3 d2 = unit_vector(unit_vector(camera_direction(p.cam, u, v)));
+        int cur = 0;
+        for (int i = 0; i < p.n_tris; ++i) {
+            const Rec16 rc = load_rec(rec, i);
+            const float dn = d2.x * rc.f[0] + d2.y * rc.f[1] + d2.z * rc.f[2];
+            const float hx = (d2.y * rc.f[5] - d2.z * rc.f[4]);
+            const float hy = (-(d2.x * rc.f[5] - d2.z * rc.f[3]));
+            const float hz = (d2.x * rc.f[4] - d2.y * rc.f[3]);
+            const float a = rc.f[6] * hx + rc.f[7] * hy + rc.f[8] * hz;
+            const float f = 1.0f / a;
+            const float uu = f * (rc.f[9] * hx + rc.f[10] * hy + rc.f[11] * hz);
+            const float vv = f * (d2.x * rc.f[12] + d2.y * rc.f[13] + d2.z * rc.f[14]);
+            const bool pass = !(dn < 0.0f) && !(a > -kTriEpsilon && a < kTriEpsilon) && !(uu < 0.0f || uu > 1.0f) &&
+                              !(vv < 0.0f || uu + vv > 1.0f);
+            while (cur < cnt && (int)(lst[cur] & 0x7fffffffu) < i) ++cur;
+            const bool in_list = cur < cnt && (int)(lst[cur] & 0x7fffffffu) == i;
+            const bool sure = in_list && (lst[cur] & kCullSureBit) != 0u;
+            const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass);
+            n_pass += (unsigned long long)__builtin_popcountll(mp);
+            if (mp != 0ull && !in_list) {
+                n_miss += (unsigned long long)__builtin_popcountll(mp);
+                if (lane == 0) atomicMax(&counters[3], ((unsigned long long)tile_id << 32) | (unsigned long long)i);
+            }
+            if (sure) n_cull += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(dn < 0.0f));
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&counters[0], n_pass);
+        atomicAdd(&counters[1], n_miss);
+        atomicAdd(&counters[2], n_cull);
+    }
+}
+
+hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
+                        const uint32_t* d_state, const TiledWork* work, unsigned long long* d_counters,
+                        hipStream_t stream) {
+    TiledWork w = *work;
+    hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    dim3 grid_bin((unsigned)((p.nx + kRegionW - 1) / kRegionW), (unsigned)((p.row_count + kRegionH - 1) / kRegionH));
+    hipLaunchKernelGGL(bin_tiles_kernel, grid_bin, dim3(kTiledThreads), 0, stream, p, d_cls, n_pad, w, kK1Max, kHeavyMin,
+                       (unsigned long long*)nullptr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)((w.tiles_x + 1) / 2), (unsigned)((w.tiles_y + 1) / 2));
+    hipLaunchKernelGGL(audit_tiles_kernel, grid, dim3(256), 0, stream, p, d_rec, d_state, w, d_counters);
+    return hipGetLastError();
+}
+
 // Self-check of reciprocal<true>: every float with biased exponent in [exp_lo, exp_hi], both
 // signs, against the compiler's IEEE 1.0f / a.
 __global__ void __launch_bounds__(256)

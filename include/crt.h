@@ -175,6 +175,15 @@ int crt_set_kernel_variant(int variant);
  * enable == 0 stops it.  Counting costs a few atomics per wavefront. */
 int crt_debug_tiled_stats(int enable, uint64_t *out24);
 
+/* Audit of the tiled variant's binning (full nx x ny image on the current device): a brute-
+ * force kernel tests every triangle against `samples` rays of every pixel (pixel-corner jitter
+ * included) and checks that each (ray, triangle) pair passing Triangle::collision_detection —
+ * closest hit or not — has its triangle in the tile's survivor list.  out4[0] = passing pairs
+ * seen, out4[1] = pairs whose triangle is missing (must be 0), out4[2] = "cull-sure" entries
+ * that saw dot(d, normal) < 0 (must be 0), out4[3] = last offender (tile << 32 | triangle). */
+int crt_debug_audit_tiles(const crt_scene *scene, const crt_camera *camera, int nx, int ny,
+                          int samples, uint64_t seed, uint64_t *out4);
+
 /* Self-check: the kernels compute f = 1.0/a (shapes/triangle.h:80) as v_rcp_f32 + one Newton
  * step when the scene is bounded (|coordinate| <= 2^38, so 2^-20 <= |a| <= 2^84 wherever f
  * is used).  This compares that sequence with the IEEE quotient for EVERY float whose biased

@@ -304,6 +304,28 @@ def test_tiled_equals_brute_force_and_oracle_on_adversarial_soups(gpu, oracle, c
         assert np.array_equal(bits(outs[name]), bits(ref)), (kind, seed, name)
 
 
+@pytest.mark.parametrize("kind", ["around_eye", "tiny_far", "huge", "mixed_scales", "random_normals", "offset_camera"])
+def test_binning_is_conservative_for_every_passing_pair(gpu, kind):
+    """Stronger than pixel equality: EVERY (ray, triangle) pair that passes the reference's
+    triangle test — closest hit or occluded — must have its triangle in the tile's list, and a
+    cull-sure entry must never see dot(d, n) < 0.  Brute-force audit on the GPU."""
+    for seed in (21, 22, 23):
+        sc = _soup_scene(kind, seed)
+        nx, ny, spp = 88, 72, 8
+        scene, cam = make(sc, nx, ny)
+        n_pass, n_missing, n_cull, offender = api.audit_tiles(scene, cam, nx, ny, spp, seed)
+        assert n_pass > 0 or kind == "tiny_far", (kind, seed)   # sub-pixel triangles may catch no ray at all
+        assert n_missing == 0 and n_cull == 0, (kind, seed, n_pass, n_missing, n_cull, offender >> 32, offender & 0xffffffff)
+
+
+def test_binning_is_conservative_on_meshes(gpu):
+    for sc, nx, ny, spp in [(scenes.cornell32(), 200, 150, 8), (scenes.displaced_sphere(60, 80), 320, 180, 4),
+                            (scenes.quad(), 64, 64, 8)]:
+        scene, cam = make(sc, nx, ny)
+        n_pass, n_missing, n_cull, _ = api.audit_tiles(scene, cam, nx, ny, spp)
+        assert n_pass > 0 and n_missing == 0 and n_cull == 0, (nx, ny, n_pass, n_missing, n_cull)
+
+
 def test_tiled_equals_brute_force_on_c3_frame(gpu, crt_built):
     """Whole 1920x1080 frame, 100 k triangles, 2 spp: tiled == brute force, bit for bit."""
     sc = scenes.bunny100k()
