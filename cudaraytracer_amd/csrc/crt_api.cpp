@@ -544,7 +544,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     int kernel_variant = 0;
     if (g_variant == 0 || g_variant == 2) kernel_variant = tiled_ok ? 1 : 0;
     else if (g_variant == 3) kernel_variant = tiled_ok ? 2 : 0;
-    else if (g_variant == 4) kernel_variant = tiled_ok ? 3 : 0;   // tiled, scalar-operand shading (A/B)
+    else if (g_variant == 4) kernel_variant = tiled_ok ? 3 : 0;   // tiled, scalar-operand walk for light tiles too (A/B)
 
     crt::RenderParams p;
     memcpy(p.cam.llc, camera->lower_left_corner, 12);

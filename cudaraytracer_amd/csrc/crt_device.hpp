@@ -77,8 +77,8 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const C
                               float4* d_cls, hipStream_t stream);
 // variant 0: brute force (every ray x every triangle); 1: tiled (conservative region/tile
 // classification + exact test on survivors); 2: tiled with tiny list capacities (tests the
-// overflow fallbacks); 3: tiled with the records fetched into VGPRs by vector loads (A/B
-// experiment, slower).  d_cls may be null for variant 0.
+// overflow fallbacks); 3: tiled with the scalar-operand walk also for light tiles (A/B of
+// the LDS-staged records).  d_cls may be null for variant 0.
 // Scratch of the tiled variant (device pointers; owned by the host layer, grow-only).
 struct TiledWork {
     uint32_t* pool;                  // survivor indices of all tiles, bump-allocated

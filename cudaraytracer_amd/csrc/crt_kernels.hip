@@ -328,28 +328,16 @@ __device__ __forceinline__ void walk_list(const float* __restrict__ rec, const u
 }
 
 // ---- the same test with the record in VGPRs.  On gfx950 a VALU instruction with an SGPR
-// operand issues at half the rate of a VGPR-only one (profiles/r1_ubench_valu*.txt), so the
-// shading kernel of the tiled variant fetches the wave-uniform record with ordinary vector
-// loads from a uniform address (4 x global_load_dwordx4, a broadcast out of L1/L2; vmcnt is
-// in order, so the next record can stay in flight while this one is evaluated).
+// operand issues at half the rate of a VGPR-only one (profiles/r1_ubench_valu*.txt).  For
+// light tiles (<= 64 survivors) the wave copies the records of its list into LDS once per tile
+// and every sample re-reads them with broadcast ds_read_b128 (uniform address): VGPR operands,
+// LDS latency instead of two dependent scalar-memory round trips.
 struct RecV {
     float4 a, b, c, d;   // n.xyz e2.x | e2.yz e1.xy | e1.z s.xyz | q.xyz tq
 };
 
-__device__ __forceinline__ RecV load_rec_v(const float* __restrict__ rec, int idx_uniform) {
-    int iv = idx_uniform & 0x7fffffff;
-    asm volatile("" : "+v"(iv));   // opaque VGPR: keeps hipcc from turning this into scalar loads
-    const char* base = reinterpret_cast<const char*>(rec);
-    const float4* r = reinterpret_cast<const float4*>(base + (size_t)((unsigned)iv * (unsigned)(kRecFloats * 4)));
-    RecV o;
-    o.a = r[0];
-    o.b = r[1];
-    o.c = r[2];
-    o.d = r[3];
-    return o;
-}
-
-__device__ __forceinline__ void exact_test_v(const RecV& rc, int i_raw, V3 d, float& closest, int& hit_idx) {
+template <bool FAST>
+__device__ __forceinline__ void exact_test_vec(const RecV& rc, int i_raw, V3 d, float& closest, int& hit_idx) {
     const int i = i_raw & 0x7fffffff;
     const float nx = rc.a.x, ny = rc.a.y, nz = rc.a.z;
     const float e2x = rc.a.w, e2y = rc.b.x, e2z = rc.b.y;
@@ -358,63 +346,29 @@ __device__ __forceinline__ void exact_test_v(const RecV& rc, int i_raw, V3 d, fl
     const float qx = rc.d.x, qy = rc.d.y, qz = rc.d.z;
     const float tq = rc.d.w;
 
-    float dn = d.x * nx + d.y * ny + d.z * nz;                         // triangle.h:61
-    bool alive = !(dn < 0.0f);
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
-
+    unsigned long long alive = __builtin_amdgcn_ballot_w64(true);
+    if (i_raw >= 0) {                                                 // not "cull-sure"
+        float dn = d.x * nx + d.y * ny + d.z * nz;                     // triangle.h:61
+        alive = __builtin_amdgcn_ballot_w64(!(dn < 0.0f));
+        if (alive == 0ull) return;
+    }
     float hx = (d.y * e2z - d.z * e2y);                               // triangle.h:71-72
     float hy = (-(d.x * e2z - d.z * e2x));
     float hz = (d.x * e2y - d.y * e2x);
     float a = e1x * hx + e1y * hy + e1z * hz;
-    alive = alive && !(a > -kTriEpsilon && a < kTriEpsilon);          // triangle.h:77
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
-
-    float f = 1.0f / a;                                               // triangle.h:80
+    alive &= __builtin_amdgcn_ballot_w64(!(fabsf(a) < kTriEpsilon));  // triangle.h:77
+    if (alive == 0ull) return;
+    float f = reciprocal<FAST>(a);                                    // triangle.h:80
     float u = f * (sx * hx + sy * hy + sz * hz);                      // triangle.h:82
-    alive = alive && !(u < 0.0f || u > 1.0f);                         // triangle.h:84
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
-
+    alive &= __builtin_amdgcn_ballot_w64(!(u < 0.0f)) & __builtin_amdgcn_ballot_w64(!(u > 1.0f));   // triangle.h:84
+    if (alive == 0ull) return;
     float v = f * (d.x * qx + d.y * qy + d.z * qz);                   // triangle.h:88
-    alive = alive && !(v < 0.0f || u + v > 1.0f);                     // triangle.h:89
-    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) return;
-
+    alive &= __builtin_amdgcn_ballot_w64(!(v < 0.0f)) & __builtin_amdgcn_ballot_w64(!(u + v > 1.0f));   // triangle.h:89
+    if (alive == 0ull) return;
     float t = f * tq;                                                 // triangle.h:92
-    if (alive && t < closest) {                                       // hitable_list.h:84
+    if (__builtin_amdgcn_inverse_ballot_w64(alive) && t < closest) {  // hitable_list.h:84
         closest = t;
         hit_idx = i;
-    }
-}
-
-// exact_test_v over list positions [k0, k1), two alternating register sets, one record ahead.
-template <class IndexAt>
-__device__ __forceinline__ void walk_v(const float* __restrict__ rec, int k0, int k1, IndexAt index_at,
-                                       V3 d, float& closest, int& hit_idx) {
-    if (k0 >= k1) return;
-    int ia = index_at(k0), ib = 0;
-    RecV A = load_rec_v(rec, ia), B = A;
-    int k = k0;
-    while (true) {
-        if (k + 1 < k1) {
-            ib = index_at(k + 1);
-            B = load_rec_v(rec, ib);
-        }
-        exact_test_v(A, ia, d, closest, hit_idx);
-        if (++k >= k1) break;
-        if (k + 1 < k1) {
-            ia = index_at(k + 1);
-            A = load_rec_v(rec, ia);
-        }
-        exact_test_v(B, ib, d, closest, hit_idx);
-        if (++k >= k1) break;
-    }
-}
-
-__device__ __forceinline__ void walk_list_v(const float* __restrict__ rec, const uint32_t* __restrict__ lst,
-                                            int k0, int k1, int lane, V3 d, float& closest, int& hit_idx) {
-    for (int base = k0; base < k1; base += 64) {
-        const int n = min(64, k1 - base);
-        const int mine = (lane < n) ? (int)lst[base + lane] : 0;
-        walk_v(rec, 0, n, [&](int k) { return __builtin_amdgcn_readlane(mine, k); }, d, closest, hit_idx);
     }
 }
 
@@ -870,6 +824,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
     __shared__ int part_i[WAVES][64];
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
+    __shared__ float4 lrec[VREC ? WAVES : 1][64][4];   // light tiles: this wave's survivor records (4 KB per wave)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -903,13 +858,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             // B1 "rays are in LDS", B2 "partial minima are in LDS".
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
-                if (VREC) {
-                    if (!walk_all) walk_list_v(rec, lst, k0, k1, lane, d2, closest, hit_idx);
-                    else walk_v(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
-                } else {
-                    if (!walk_all) walk_list<true>(rec, lst, k0, k1, lane, d2, closest, hit_idx);
-                    else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
-                }
+                if (!walk_all) walk_list<true>(rec, lst, k0, k1, lane, d2, closest, hit_idx);
+                else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
               }
             };
             if (wave == 0) {
@@ -976,13 +926,35 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
         // the whole list of a light tile fits one or two VGPRs (lane j holds positions j, 64+j)
         const int mine0 = (lane < cnt) ? (int)lst[lane] : 0;
         const int mine1 = (64 + lane < cnt) ? (int)lst[64 + lane] : 0;
+        if (VREC) {   // stage the records of the list in this wave's LDS area (all 64 lanes, before any lane leaves)
+            if (lane < min(cnt, 64)) {
+                const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(mine0 & 0x7fffffff) * kRecFloats);
+                lrec[wave][lane][0] = r[0];
+                lrec[wave][lane][1] = r[1];
+                lrec[wave][lane][2] = r[2];
+                lrec[wave][lane][3] = r[3];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         if (x < p.nx && ly < p.row_count) {
             render_pixel(p, x, ly, shade_n, state, rgb, true,
                          [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (VREC) {
-                    walk_v(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
-                    walk_v(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
+                    const int n0 = min(cnt, 64);
+                    for (int k = 0; k < n0; ++k) {
+                        RecV rc;
+                        rc.a = lrec[wave][k][0];
+                        rc.b = lrec[wave][k][1];
+                        rc.c = lrec[wave][k][2];
+                        rc.d = lrec[wave][k][3];
+                        // consumed together: four broadcast ds_read_b128 in flight, one wait
+                        asm volatile("" : "+v"(rc.a.x), "+v"(rc.a.w), "+v"(rc.b.x), "+v"(rc.b.w), "+v"(rc.c.x), "+v"(rc.c.w), "+v"(rc.d.x), "+v"(rc.d.w));
+                        exact_test_vec<true>(rc, __builtin_amdgcn_readlane(mine0, k), d2, closest, hit_idx);
+                    }
+                    walk<true>(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
                 } else {
                     walk<true>(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
                     walk<true>(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
@@ -1083,31 +1055,25 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     dim3 grid_shade((unsigned)std::max(1, std::min(n_cus * blocks_per_cu, w.tiles_total)));
     // Waves that share a heavy tile: 8 when the launch has plenty of tiles per CU (throughput),
     // 16 when it is small (a rank of a multi-GPU split): then the longest tile bounds the time.
-    int occ = 8, dbg_repeat = 1, group = (w.tiles_total >= n_cus * 96) ? 8 : 16;
+    int dbg_repeat = 1, group = (w.tiles_total >= n_cus * 96) ? 8 : 16;
+    int occ = (group == 8) ? 6 : 8;   // measured optimum with the LDS-staged light tiles
     if (const char* e = getenv("CRT_SHADE_OCC")) occ = atoi(e);
     if (const char* e = getenv("CRT_SHADE_GROUP")) group = atoi(e);              // waves that share a heavy tile
     if (const char* e = getenv("CRT_DEBUG_WALK_REPEAT")) dbg_repeat = atoi(e);   // timing experiments only
-    if (variant == 3) {
-        hipLaunchKernelGGL((shade_tiles_kernel<true, 4, 16>), grid_shade, dim3(1024), 0, stream, p, d_rec, d_shade_n,
-                           d_state, d_rgb, w, d_stats, dbg_repeat);
-    } else if (group == 8) {
-        dim3 g8((unsigned)std::max(1, std::min(n_cus * blocks_per_cu * 2, w.tiles_total)));
-        if (occ == 4)
-            hipLaunchKernelGGL((shade_tiles_kernel<false, 4, 8>), g8, dim3(512), 0, stream, p, d_rec, d_shade_n, d_state,
-                               d_rgb, w, d_stats, dbg_repeat);
-        else if (occ == 6)
-            hipLaunchKernelGGL((shade_tiles_kernel<false, 6, 8>), g8, dim3(512), 0, stream, p, d_rec, d_shade_n, d_state,
-                               d_rgb, w, d_stats, dbg_repeat);
-        else
-            hipLaunchKernelGGL((shade_tiles_kernel<false, 8, 8>), g8, dim3(512), 0, stream, p, d_rec, d_shade_n, d_state,
-                               d_rgb, w, d_stats, dbg_repeat);
-    } else if (occ == 4) {
-        hipLaunchKernelGGL((shade_tiles_kernel<false, 4, 16>), grid_shade, dim3(1024), 0, stream, p, d_rec, d_shade_n,
-                           d_state, d_rgb, w, d_stats, dbg_repeat);
+    bool vrec = variant != 3;   // light tiles: records staged in LDS (VGPR operands); variant 3 keeps the scalar-operand walk (A/B)
+    if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
+    const dim3 g8((unsigned)std::max(1, std::min(n_cus * blocks_per_cu * 2, w.tiles_total)));
+#define CRT_LAUNCH_SHADE(V, O, W_, GRID)                                                                              \
+    hipLaunchKernelGGL((shade_tiles_kernel<V, O, W_>), GRID, dim3(W_ * 64), 0, stream, p, d_rec, d_shade_n, d_state, \
+                       d_rgb, w, d_stats, dbg_repeat)
+    if (group == 8) {
+        if (vrec) { if (occ == 6) CRT_LAUNCH_SHADE(true, 6, 8, g8); else if (occ == 4) CRT_LAUNCH_SHADE(true, 4, 8, g8); else CRT_LAUNCH_SHADE(true, 8, 8, g8); }
+        else      { if (occ == 6) CRT_LAUNCH_SHADE(false, 6, 8, g8); else if (occ == 4) CRT_LAUNCH_SHADE(false, 4, 8, g8); else CRT_LAUNCH_SHADE(false, 8, 8, g8); }
     } else {
-        hipLaunchKernelGGL((shade_tiles_kernel<false, 8, 16>), grid_shade, dim3(1024), 0, stream, p, d_rec, d_shade_n,
-                           d_state, d_rgb, w, d_stats, dbg_repeat);
+        if (vrec) { if (occ == 4) CRT_LAUNCH_SHADE(true, 4, 16, grid_shade); else CRT_LAUNCH_SHADE(true, 8, 16, grid_shade); }
+        else      { if (occ == 4) CRT_LAUNCH_SHADE(false, 4, 16, grid_shade); else CRT_LAUNCH_SHADE(false, 8, 16, grid_shade); }
     }
+#undef CRT_LAUNCH_SHADE
     return hipGetLastError();
 }
 

@@ -161,8 +161,8 @@ int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
 /* Kernel selection (diagnostics / A-B benchmarking), per calling thread. 0 = auto (default:
  * tiled when the scene and camera are finite and |coordinate| <= 2^38, else brute force),
  * 1 = brute-force list walk, 2 = tiled, 3 = tiled with tiny survivor-list capacities (test
- * hook for the overflow fallbacks), 4 = tiled with the triangle records fetched into VGPRs
- * by vector loads instead of SGPRs by scalar loads (A/B experiment; slower).  All variants produce identical pixels.  Returns the previous value. */
+ * hook for the overflow fallbacks), 4 = tiled with scalar-operand (SGPR) triangle records
+ * also for light tiles instead of the LDS-staged VGPR records (A/B).  All variants produce identical pixels.  Returns the previous value. */
 int crt_set_kernel_variant(int variant);
 
 /* Diagnostics of the tiled variant, per calling thread.  out24 (nullable, 48 words) first receives

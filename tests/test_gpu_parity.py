@@ -16,12 +16,17 @@ pytestmark = pytest.mark.gpu
 def gpu(crt_built):
     if crt_built.crt_device_count() < 1:
         pytest.fail("no HIP device visible: the product has no CPU fallback")
+    import time
     import torch
+    for _ in range(5):                     # a fresh box can take a moment to expose the device to torch
+        if torch.cuda.is_available():
+            break
+        time.sleep(2.0)
     assert torch.cuda.is_available()
     return torch
 
 
-VARIANTS = {"brute": 1, "tiled": 2, "tiled_tinycaps": 3, "tiled_vector_records": 4}
+VARIANTS = {"brute": 1, "tiled": 2, "tiled_tinycaps": 3, "tiled_scalar_light": 4}
 
 
 @pytest.fixture(params=sorted(VARIANTS))
