@@ -856,9 +856,34 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             // Master/worker: wave 0 owns the pixels' RNG streams, generates the 64 rays of each
             // sample and shades; the other 15 waves only trace.  Two barriers per sample:
             // B1 "rays are in LDS", B2 "partial minima are in LDS".
+            // this wave's slice: the first 64 entries are staged in LDS like a light tile's list
+            const int n_lds = (VREC && !walk_all) ? min(64, k1 - k0) : 0;
+            int slice_mine = 0;
+            if (n_lds > 0) {
+                slice_mine = (lane < n_lds) ? (int)lst[k0 + lane] : 0;
+                if (lane < n_lds) {
+                    const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(slice_mine & 0x7fffffff) * kRecFloats);
+                    lrec[wave][lane][0] = r[0];
+                    lrec[wave][lane][1] = r[1];
+                    lrec[wave][lane][2] = r[2];
+                    lrec[wave][lane][3] = r[3];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
-                if (!walk_all) walk_list<true>(rec, lst, k0, k1, lane, d2, closest, hit_idx);
+                for (int k = 0; k < n_lds; ++k) {
+                    RecV rc;
+                    rc.a = lrec[wave][k][0];
+                    rc.b = lrec[wave][k][1];
+                    rc.c = lrec[wave][k][2];
+                    rc.d = lrec[wave][k][3];
+                    asm volatile("" : "+v"(rc.a.x), "+v"(rc.a.w), "+v"(rc.b.x), "+v"(rc.b.w), "+v"(rc.c.x), "+v"(rc.c.w), "+v"(rc.d.x), "+v"(rc.d.w));
+                    exact_test_vec<true>(rc, __builtin_amdgcn_readlane(slice_mine, k), d2, closest, hit_idx);
+                }
+                if (!walk_all) walk_list<true>(rec, lst, k0 + n_lds, k1, lane, d2, closest, hit_idx);
                 else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
               }
             };
