@@ -557,6 +557,8 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     p.strip_rows = strip_rows; p.strip_step = strip_step;
     p.n_tris = scene->n_tris;
     p.rng_count = count;
+    p.inv_nx = 1.0 / (double)(float)nx;
+    p.inv_ny = 1.0 / (double)(float)ny;
 
     if (!g_ev_start) {
         HIP_TRY(hipEventCreate(&g_ev_start));
@@ -600,6 +602,8 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     p.strip_rows = 32; p.strip_step = 1;
     p.n_tris = scene->n_tris;
     p.rng_count = (long long)nx * ny;
+    p.inv_nx = 1.0 / (double)(float)nx;
+    p.inv_ny = 1.0 / (double)(float)ny;
     unsigned long long* d = nullptr;
     int rc = ensure_workspace(nx, ny);
     hipError_t e = (rc == CRT_OK) ? hipMalloc(&d, 4 * sizeof(unsigned long long)) : hipErrorUnknown;
@@ -640,15 +644,22 @@ int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords =
     return CRT_OK;
 }
 
+int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t* mismatches);
+
 int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t* mismatches) {
+    return crt_debug_check_division(0, exp_lo, exp_hi, mismatches);
+}
+
+int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t* mismatches) {
     // Exhaustive self-check of the 3-instruction reciprocal used by the kernels on bounded
     // scenes: all floats with biased exponent in [exp_lo, exp_hi], both signs.
-    if (!mismatches || exp_lo < 0 || exp_hi > 255 || exp_lo > exp_hi) return fail(CRT_ERR_INVALID, "crt_debug_check_reciprocal: bad range");
+    if (!mismatches || exp_lo < 0 || exp_hi > 255 || exp_lo > exp_hi || mode < 0 || mode > 2)
+        return fail(CRT_ERR_INVALID, "crt_debug_check_reciprocal: bad range");
     if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_debug_check_reciprocal: no HIP device");
     unsigned long long* d = nullptr;
     HIP_TRY(hipMalloc(&d, sizeof(unsigned long long)));
     hipError_t e = hipMemset(d, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = crt::launch_check_reciprocal((uint32_t)exp_lo, (uint32_t)exp_hi, d, nullptr);
+    if (e == hipSuccess) e = crt::launch_check_reciprocal(mode, (uint32_t)exp_lo, (uint32_t)exp_hi, d, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     unsigned long long h = 0;
     if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);

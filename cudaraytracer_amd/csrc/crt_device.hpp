@@ -54,6 +54,7 @@ struct RenderParams {
     int strip_rows, strip_step;
     int n_tris;
     long long rng_count;         // number of states = row_count * nx (SoA stride); element = ly * nx + x
+    double inv_nx, inv_ny;       // 1.0 / double(float(nx)), 1.0 / double(float(ny)) (host, correctly rounded)
 };
 
 __host__ __device__ inline int global_row(int row_begin, int strip_rows, int strip_step, int ly) {
@@ -105,7 +106,8 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
 hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                         const uint32_t* d_state, const TiledWork* work, unsigned long long* d_counters,
                         hipStream_t stream);
-hipError_t launch_check_reciprocal(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad, hipStream_t stream);
+hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad,
+                                   hipStream_t stream);
 constexpr int kStatsWords = 48;
 
 }  // namespace crt

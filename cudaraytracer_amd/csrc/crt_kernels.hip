@@ -169,6 +169,30 @@ struct V3 {
     float x, y, z;
 };
 
+// ---- correctly rounded fp32 quotients through fp64 (used only in the tiled shading kernel).
+// For floats x, y the quotient x/y is either a float or at least 2^-49 (relative) away from
+// every midpoint of two adjacent floats: x - m*y is a non-zero multiple of
+// ulp(m)*ulp(y)/2 for a midpoint m, and m*y cannot be a float unless y is a power of two
+// (then x/y is exact).  Hence RN24(x * r) == RN24(x / y) for ANY double r with
+// |r - 1/y| <= 2^-50/|y| : one fp64 reciprocal serves the three components of unit_vector,
+// and a host-computed 1.0/double(nx) serves `(x + U) / float(nx)` (core/render.h:116-117).
+// rcp64_of_float: v_rcp_f64 + two Newton steps; its accuracy (<= 2 ulp of fp64 = 2^-51) is
+// checked for EVERY positive normal float by crt_debug_check_reciprocal (mode 1).
+__device__ __forceinline__ double rcp64_of_float(float y) {
+    const double yd = (double)y;
+    double r = __builtin_amdgcn_rcp(yd);
+    double e = __builtin_fma(-yd, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-yd, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+__device__ __forceinline__ float mul_round(float x, double r) { return (float)((double)x * r); }
+
+// unit_vector through the fp64 reciprocal; identical bits to unit_vector below whenever the
+// length is an ordinary float (2^-100 < len < 2^100), else the IEEE divides.
+__device__ __forceinline__ V3 unit_vector_fast(V3 v);
+
 // unit_vector(v) = v / v.length()  (core/vec3.h:191-193,38-40,105-107): three IEEE divides.
 __device__ __forceinline__ V3 unit_vector(V3 v) {
     float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
@@ -183,6 +207,14 @@ __device__ __forceinline__ V3 camera_direction(const CameraPOD& c, float u, floa
     d.y = ((c.llc[1] + u * c.horizontal[1]) + v * c.vertical[1]) - c.origin[1];
     d.z = ((c.llc[2] + u * c.horizontal[2]) + v * c.vertical[2]) - c.origin[2];
     return d;
+}
+
+__device__ __forceinline__ V3 unit_vector_fast(V3 v) {
+    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const bool ordinary = len > 7.8886090522101181e-31f && len < 1.2676506002282294e30f;   // 2^-100 .. 2^100
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return V3{v.x / len, v.y / len, v.z / len};
+    const double r = rcp64_of_float(len);
+    return V3{mul_round(v.x, r), mul_round(v.y, r), mul_round(v.z, r)};
 }
 
 // backgroundSky (core/render.h:41-46) given v = unit_vector(d0) already.
@@ -377,7 +409,7 @@ __device__ __forceinline__ void exact_test_vec(const RecV& rc, int i_raw, V3 d, 
 // (hitable/hitable_list.h:76-91): minimum t over all triangles that pass
 // Triangle::collision_detection (any sign of t, no range test), lowest index on ties, NaN
 // never accepted.
-template <class Traverse>
+template <bool FASTDIV = false, class Traverse>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly,
                                              const float* __restrict__ shade_n,
                                              uint32_t* __restrict__ state, float* __restrict__ rgb,
@@ -400,8 +432,14 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
     const float fnx = (float)p.nx, fny = (float)p.ny;
 
     for (int smp = 0; smp < p.samples; ++smp) {
-        float u = ((float)x + xw_uniform(rs)) / fnx;                   // render.h:116
-        float v = ((float)y + xw_uniform(rs)) / fny;                   // render.h:117
+        float u, v;
+        if (FASTDIV) {   // same bits as the IEEE divides (see rcp64_of_float)
+            u = mul_round((float)x + xw_uniform(rs), p.inv_nx);        // render.h:116
+            v = mul_round((float)y + xw_uniform(rs), p.inv_ny);        // render.h:117
+        } else {
+            u = ((float)x + xw_uniform(rs)) / fnx;                     // render.h:116
+            v = ((float)y + xw_uniform(rs)) / fny;                     // render.h:117
+        }
         // get_ray(u, v, state): the lens sample comes from state[0] (render.h:118,
         // camera.h:6-13,41).  With lens_radius == 0 only its side effect on stream 0
         // exists; under serial-order semantics only pixel 0 observes it.
@@ -417,8 +455,8 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 
         // world list Transform then triangle Transform: ScaleRay normalises twice
         // (transform.h:50-54 via hitable.h:34 at both levels).
-        V3 d1 = unit_vector(d0);
-        V3 d2 = unit_vector(d1);
+        V3 d1 = FASTDIV ? unit_vector_fast(d0) : unit_vector(d0);
+        V3 d2 = FASTDIV ? unit_vector_fast(d1) : unit_vector(d1);
 
         float closest = FLT_MAX;   // double closest_so_far = t_max (FLT_MAX), hitable_list.h:82
         int hit_idx = -1;
@@ -889,7 +927,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             };
             if (wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
-                render_pixel(p, x, ly, shade_n, state, rgb, lane_valid,
+                render_pixel<true>(p, x, ly, shade_n, state, rgb, lane_valid,
                              [&](V3 d2, float& closest, int& hit_idx) {
                     ray_d[0][lane] = d2.x;
                     ray_d[1][lane] = d2.y;
@@ -964,7 +1002,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (x < p.nx && ly < p.row_count) {
-            render_pixel(p, x, ly, shade_n, state, rgb, true,
+            render_pixel<true>(p, x, ly, shade_n, state, rgb, true,
                          [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (VREC) {
@@ -1200,8 +1238,41 @@ check_reciprocal_kernel(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* __
     if (mine) atomicAdd(bad, mine);
 }
 
-hipError_t launch_check_reciprocal(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad, hipStream_t stream) {
-    hipLaunchKernelGGL(check_reciprocal_kernel, dim3(4096), dim3(256), 0, stream, exp_lo, exp_hi, d_bad);
+// mode 1: |rcp64_of_float(y) - 1/y| <= 2 ulp(fp64) for every float of the exponent range;
+// mode 2: mul_round(x, rcp64_of_float(y)) == x / y for 64 pseudo-random numerators x per y.
+__global__ void __launch_bounds__(256)
+check_division_kernel(int mode, uint32_t exp_lo, uint32_t exp_hi, unsigned long long* __restrict__ bad) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long total = (unsigned long long)(exp_hi - exp_lo + 1) << 24;
+    unsigned long long mine = 0;
+    for (; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t bits = ((uint32_t)(i & 1) << 31) | ((exp_lo + (uint32_t)(i >> 24)) << 23) | (uint32_t)((i >> 1) & 0x7fffff);
+        const float y = __uint_as_float(bits);
+        const double r = rcp64_of_float(y), ref = 1.0 / (double)y;
+        if (mode == 1) {
+            const long long d = (long long)__double_as_longlong(r) - (long long)__double_as_longlong(ref);
+            mine += (d > 2 || d < -2) ? 1ull : 0ull;
+        } else {
+            uint32_t h = bits * 2654435761u + 12345u;
+            for (int k = 0; k < 64; ++k) {
+                h = h * 1664525u + 1013904223u;
+                // numerator: random mantissa, exponent within +-40 of y's (quotients from 2^-40 to 2^40), random sign
+                const uint32_t ex = (uint32_t)((int)(exp_lo + (uint32_t)(i >> 24)) + (int)((h >> 9) % 81u) - 40);
+                const float x = __uint_as_float(((h & 1u) << 31) | ((ex & 0xffu) << 23) | ((h >> 8) & 0x7fffffu));
+                if (ex == 0u || ex >= 255u) continue;
+                mine += (__float_as_uint(mul_round(x, r)) != __float_as_uint(x / y)) ? 1ull : 0ull;
+            }
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad,
+                                   hipStream_t stream) {
+    if (mode == 0)
+        hipLaunchKernelGGL(check_reciprocal_kernel, dim3(4096), dim3(256), 0, stream, exp_lo, exp_hi, d_bad);
+    else
+        hipLaunchKernelGGL(check_division_kernel, dim3(4096), dim3(256), 0, stream, mode, exp_lo, exp_hi, d_bad);
     return hipGetLastError();
 }
 

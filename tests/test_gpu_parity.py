@@ -78,6 +78,17 @@ def test_fast_reciprocal_is_exact(gpu, crt_built):
     assert bad.value == 0
 
 
+def test_fp64_reciprocal_quotients_are_exact(gpu, crt_built):
+    """x/len and (x+U)/nx are computed as float(double(x) * r64) in the shading kernel: r64 must
+    be within 2 ulp(fp64) of 1/y for EVERY float y in 2^-100..2^100 (this implies correct rounding
+    of every quotient, see csrc), and a direct comparison on 64 numerators per y must agree."""
+    bad = C.c_uint64(123)
+    assert crt_built.crt_debug_check_division(1, 27, 227, C.byref(bad)) == 0
+    assert bad.value == 0
+    assert crt_built.crt_debug_check_division(2, 107, 147, C.byref(bad)) == 0     # 2^-20 .. 2^20, 4.4e10 quotients
+    assert bad.value == 0
+
+
 def test_unbounded_scene_uses_ieee_division_and_brute_force(gpu, oracle, crt_built):
     """Coordinates beyond 2^38: no tiling, no fast reciprocal — still the reference's pixels."""
     sc = scenes.random_soup(40, 5)
