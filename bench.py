@@ -93,8 +93,8 @@ def cpu_baseline(obj_path, budget_rays=1536):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--variant", type=int, default=0, help=argparse.SUPPRESS)
