@@ -165,15 +165,19 @@ int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
  * also for light tiles instead of the LDS-staged VGPR records (A/B).  All variants produce identical pixels.  Returns the previous value. */
 int crt_set_kernel_variant(int variant);
 
-/* Diagnostics of the tiled variant, per calling thread.  out24 (nullable, 48 words) first receives
- * the counters accumulated since the last enable: [0] regions, [1] sum and [2] max of the
- * region survivor count, [3] region-list overflows, [4] tiles, [5] sum and [6] max of the
- * tile survivor count, [7] tile-list overflows, [8..23] histogram of the tile survivor count
- * (bucket b counts tiles with 2^(b-1) <= n < 2^b), [24..27] summed block cycles (s_memtime) of
- * phase A / A2 / B-light / B-heavy, [28..30] max block cycles total / B-light / B-heavy.
- * Then enable != 0 (re)starts counting,
- * enable == 0 stops it.  Counting costs a few atomics per wavefront. */
-int crt_debug_tiled_stats(int enable, uint64_t *out24);
+/* Diagnostics of the tiled variant, per calling thread.  out48 (nullable, 48 words) first
+ * receives the counters accumulated since the last enable:
+ *   [0] regions, [1] sum and [2] max of the region survivor count, [3] region-list overflows,
+ *   [4] tiles, [5] sum and [6] max of the tile survivor count, [7] pool overflows,
+ *   [8..23] histogram of the tile survivor count (bucket b: 2^(b-1) <= n < 2^b),
+ *   shading kernel cycles (s_memtime): [24] heavy phase summed over blocks, [25] its max,
+ *   [26] light phase summed over waves, [27] its max, [28] max wave total,
+ *   binning kernel cycles: [29] phase A summed over blocks, [30] its max, [31] slowest wave of
+ *   phase A2; master wave of shared tiles: [32] set-up+merge+shade, [33] own trace, [34] wait
+ *   at the second barrier (cycles summed over [35] tiles with [36] survivors in total).
+ * Then enable != 0 (re)starts counting, enable == 0 stops it.  Counting costs a few atomics
+ * and clock reads per wavefront. */
+int crt_debug_tiled_stats(int enable, uint64_t *out48);
 
 /* Audit of the tiled variant's binning (full nx x ny image on the current device): a brute-
  * force kernel tests every triangle against `samples` rays of every pixel (pixel-corner jitter
