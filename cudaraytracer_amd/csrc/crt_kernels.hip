@@ -846,6 +846,16 @@ bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, Tile
     }
 }
 
+// (t, index) as one 64-bit key whose unsigned order is the reference's accept order: smaller t
+// first (IEEE order of non-NaN floats; -0 is folded into +0 because the reference's `<` does not
+// separate them), lower triangle index on equal t (hitable_list.h:84 walks in index order with
+// a strict <).  Accepted hits never carry a NaN t.
+__device__ __forceinline__ unsigned long long hit_key(float t, int idx) {
+    const unsigned b = __float_as_uint(t + 0.0f);
+    const unsigned ordered = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)ordered << 32) | (unsigned long long)(unsigned)idx;
+}
+
 // ---- kernel 2 of the tiled variant: shading.  Persistent 1024-thread blocks pull tiles
 // from the work queues.  Heavy tiles (classes 0-2, heaviest first) are traced by all 16
 // waves of a block together: every wave traces the same 64 rays against its own slice of
@@ -858,8 +868,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* __restrict__ shade_n,
                    uint32_t* __restrict__ state, float* __restrict__ rgb, TiledWork w,
                    unsigned long long* __restrict__ stats, int dbg_repeat) {
-    __shared__ float part_t[WAVES][64];
-    __shared__ int part_i[WAVES][64];
+    __shared__ unsigned long long best_key[64];   // per pixel: min over the waves of (ordered t, index)
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
     __shared__ float4 lrec[VREC ? WAVES : 1][64][4];   // light tiles: this wave's survivor records (4 KB per wave)
@@ -932,22 +941,17 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                     ray_d[0][lane] = d2.x;
                     ray_d[1][lane] = d2.y;
                     ray_d[2][lane] = d2.z;
+                    best_key[lane] = ~0ull;
                     long long tc0 = 0, tc1 = 0, tc2 = 0;
                     if (stats) { tc0 = (long long)clock64(); tc_setup += tc0 - tc_prev; }
                     __syncthreads();   // B1
                     trace_slice(d2, closest, hit_idx);
+                    if (hit_idx >= 0) atomicMin(&best_key[lane], hit_key(closest, hit_idx));
                     if (stats) tc1 = (long long)clock64();
                     __syncthreads();   // B2
                     if (stats) { tc2 = (long long)clock64(); tc_trace += tc1 - tc0; tc_wait += tc2 - tc1; tc_prev = tc2; }
-#pragma unroll
-                    for (int k = 1; k < WAVES; ++k) {
-                        const float tw = part_t[k][lane];
-                        const int iw = part_i[k][lane];
-                        if (iw >= 0 && tw < closest) {   // strict <: the lower slice (lower index) keeps ties
-                            closest = tw;
-                            hit_idx = iw;
-                        }
-                    }
+                    const unsigned long long kbest = best_key[lane];
+                    hit_idx = (kbest == ~0ull) ? -1 : (int)(unsigned)(kbest & 0xffffffffull);
                 });
                 if (stats && lane == 0) {   // master-wave time split: (merge+shade+next setup), own trace, wait for the slowest slice
                     atomicAdd(&stats[32], (unsigned long long)tc_setup);
@@ -963,8 +967,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                     float closest = FLT_MAX;
                     int hit_idx = -1;
                     trace_slice(d2, closest, hit_idx);
-                    part_t[wave][lane] = closest;
-                    part_i[wave][lane] = hit_idx;
+                    if (hit_idx >= 0) atomicMin(&best_key[lane], hit_key(closest, hit_idx));
                     __syncthreads();   // B2
                 }
             }
