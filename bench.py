@@ -200,12 +200,22 @@ def main():
         achieved = alg / (k_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this very
         # command (tools/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         pmc = os.path.join(ROOT, "profiles", "r1_tiled", "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin"))
         if tiled and world == 1 and args.spp == SPP and os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc))["derived"]["hbm_traffic_bytes_corrected"]
+                summary = json.load(open(pmc))
+                traffic = summary["derived"]["hbm_traffic_bytes_corrected"]
                 traffic_src = os.path.relpath(pmc, ROOT)
+                # what actually bounds the kernel: VALU issue.  SQ_INSTS_VALU per launch (rocprofv3 PMC
+                # pass) over this run's kernel time; peak = 1 wave64 VALU instruction per 2.25 cycles per
+                # SIMD, measured on this chip for VGPR-only v_mul/v_add (profiles/r1_ubench_valu2.txt)
+                insts = summary["per_launch_counters"].get("SQ_INSTS_VALU")
+                if insts:
+                    rate = insts / (k_ms * 1e-3) / 1024 / 2.4e9
+                    valu = {"unit": "wave64 VALU instructions per clock per SIMD", "achieved": rate,
+                            "peak": 1 / 2.25, "frac": rate * 2.25, "insts_per_launch": insts,
+                            "source": os.path.relpath(pmc, ROOT)}
             except Exception:
                 traffic = None
         out = {
@@ -225,6 +235,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "algorithmic_bytes_per_launch": alg},
+            "valu_issue": valu,
             "kernels": kernels,
             "survivors": survivors,
         }
