@@ -1128,7 +1128,9 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* e = getenv("CRT_DEBUG_WALK_REPEAT")) dbg_repeat = atoi(e);   // timing experiments only
     bool vrec = variant != 3;   // light tiles: records staged in LDS (VGPR operands); variant 3 keeps the scalar-operand walk (A/B)
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
-    const dim3 g8((unsigned)std::max(1, std::min(n_cus * blocks_per_cu * 2, w.tiles_total)));
+    int g8n = n_cus * blocks_per_cu * 2;
+    if (const char* e = getenv("CRT_SHADE_GRID")) g8n = std::max(1, atoi(e));
+    const dim3 g8((unsigned)std::max(1, std::min(g8n, w.tiles_total)));
 #define CRT_LAUNCH_SHADE(V, O, W_, GRID)                                                                              \
     hipLaunchKernelGGL((shade_tiles_kernel<V, O, W_>), GRID, dim3(W_ * 64), 0, stream, p, d_rec, d_shade_n, d_state, \
                        d_rgb, w, d_stats, dbg_repeat)

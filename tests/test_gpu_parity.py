@@ -377,3 +377,28 @@ def test_c3_crop_and_band_properties(gpu, oracle):
     b, c = partition_rows(ny, 8, 3)
     (band,), _ = hip_render_with_states(gpu, scene, cam, nx, ny, spp, row_begin=b, row_count=c)
     assert np.array_equal(bits(band), bits(full[b:b + c]))
+
+
+def test_c5_geometry_band_and_crop(gpu, oracle, crt_built):
+    """configs[4] geometry (3840x2160, 1 M triangles) at 1 spp: a 64-row band of the tiled kernels
+    equals the brute-force kernel bit for bit (incl. RNG states), and a 16x2 crop equals the oracle."""
+    sc = scenes.dragon1m()
+    nx, ny, spp = 3840, 2160, 1
+    scene, cam = make(sc, nx, ny)
+    assert scene.n_triangles == 1000000
+    rb, rc = 1040, 64
+    outs = []
+    for v in (2, 1):
+        prev = crt_built.crt_set_kernel_variant(v)
+        try:
+            (o,), st = hip_render_with_states(gpu, scene, cam, nx, ny, spp, row_begin=rb, row_count=rc)
+        finally:
+            crt_built.crt_set_kernel_variant(prev)
+        outs.append((o, st))
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    w, ocam = oracle_pair(oracle, sc, nx, ny)
+    win = (rb + 30, rb + 32, 1900, 1916)
+    ref, _ = oracle.render(w, ocam, nx, ny, spp, window=win)
+    r0, r1, c0, c1 = win
+    assert np.array_equal(bits(outs[0][0][r0 - rb:r1 - rb, c0:c1]), bits(ref[r0:r1, c0:c1]))
