@@ -87,8 +87,11 @@ int ensure_workspace(int nx, int rows) {
         if (ws.w.queue) (void)hipFree(ws.w.queue);
         ws.w.tile_desc = nullptr;
         ws.w.queue = nullptr;
+        if (ws.w.tile_count) (void)hipFree(ws.w.tile_count);
+        ws.w.tile_count = nullptr;
         HIP_TRY(hipMalloc(&ws.w.tile_desc, tiles * sizeof(uint2)));
         HIP_TRY(hipMalloc(&ws.w.queue, crt::kClasses * tiles * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&ws.w.tile_count, tiles * sizeof(uint32_t)));
         ws.tiles = tiles;
     }
     ws.w.pool_cap = (uint32_t)std::min<size_t>(ws.pool_entries, 0xfffffff0u);
@@ -96,6 +99,64 @@ int ensure_workspace(int nx, int rows) {
     ws.w.tiles_y = tiles_y;
     ws.w.tiles_total = (int)tiles;
     return CRT_OK;
+}
+
+// Slacks of the tiled classification, from the camera alone.
+// Position slack: the reference evaluates d0 = llc + u*H + v*V - o in float; every component is
+// within delta0 = 2^-21 * mag of the exact affine model (4 roundings of intermediates <= mag =
+// |llc|+|H|+|V|+|o|, with a factor 2 to spare).  With B = [H V c], c = model(0.5, 0.5), and
+// delta = B (alpha, beta, gamma)^T:
+//   model(u,v) + delta = (1+gamma) * model(u + du', v + dv'),  du' = (alpha - gamma (u - 0.5)) / (1 + gamma)
+// so the float direction is a positive multiple of the model direction of a point at most
+// (du, dv) away — the binning widens every rectangle by that much.
+// Value slack K (times the 1-norm product M of a form): normalisation and float evaluation of
+// the dot/cross chains, <= 2^-21.1 |d0| M, budgeted 2^-19 |d0|; fp32 rounding of the affine
+// coefficients and of the classification FMAs, <= 2^-22 mag0 M, budgeted 2^-21 mag0
+// (mag0 = |llc-o|_1 + |H|_1 + |V|_1 >= |A|/M, |B|/M, |C|/M).
+// false: ill-conditioned camera (the caller then uses the brute-force kernel).
+bool camera_slacks(const crt_camera* cam, float* du, float* dv, float* K) {
+    double H[3], V[3], c[3], p0[3], mag = 0.0, mag0 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        H[k] = cam->horizontal[k];
+        V[k] = cam->vertical[k];
+        p0[k] = (double)cam->lower_left_corner[k] - (double)cam->origin[k];
+        c[k] = p0[k] + 0.5 * H[k] + 0.5 * V[k];
+        mag = std::max(mag, std::fabs((double)cam->lower_left_corner[k]) + std::fabs(H[k]) + std::fabs(V[k]) +
+                                std::fabs((double)cam->origin[k]));
+        mag0 += std::fabs(p0[k]) + std::fabs(H[k]) + std::fabs(V[k]);
+    }
+    const double delta0 = mag * 4.76837158203125e-7;   // 2^-21
+    auto cross = [](const double* a, const double* b, double* o) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    double r0[3], r1[3], r2[3];   // rows of B^-1 times det
+    cross(V, c, r0);
+    cross(c, H, r1);
+    cross(H, V, r2);
+    const double det = H[0] * r0[0] + H[1] * r0[1] + H[2] * r0[2];
+    if (!std::isfinite(det) || det == 0.0) return false;
+    auto norm1 = [&](const double* r) { return (std::fabs(r[0]) + std::fabs(r[1]) + std::fabs(r[2])) / std::fabs(det); };
+    const double a = norm1(r0) * delta0, b = norm1(r1) * delta0, g = norm1(r2) * delta0;
+    if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(g) || g > 0.25) return false;
+    const double su = (a + 0.5 * g) / (1.0 - g) * 1.01, sv = (b + 0.5 * g) / (1.0 - g) * 1.01;
+    if (!(su < 1.0) || !(sv < 1.0)) return false;      // a slack of the whole screen: nothing to gain
+    // |d0_float| over the screen: the model is affine, its norm is largest at a corner
+    double len_hi = 0.0;
+    for (int corner = 0; corner < 4; ++corner) {
+        double n2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double d = p0[k] + ((corner & 1) ? H[k] : 0.0) + ((corner & 2) ? V[k] : 0.0);
+            n2 += d * d;
+        }
+        len_hi = std::max(len_hi, std::sqrt(n2));
+    }
+    len_hi = (len_hi + 1.7320508075688772 * delta0) * 1.0001;
+    const double k_slack = (1.9073486328125e-6 * len_hi + 4.76837158203125e-7 * mag0 * 1.0001) * 1.001;   // 2^-19, 2^-21
+    if (!std::isfinite(k_slack) || k_slack > 1.0e30) return false;
+    *du = (float)su * 1.000001f;
+    *dv = (float)sv * 1.000001f;
+    *K = (float)k_slack * 1.000001f;
+    return true;
 }
 
 bool have_device() {
@@ -531,6 +592,12 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
                     rng->first, rng->count, rng->strip_step, first, count, strip_step);
     hipStream_t stream = (hipStream_t)stream_;
 
+    if (!g_ev_start) {
+        HIP_TRY(hipEventCreate(&g_ev_start));
+        HIP_TRY(hipEventCreate(&g_ev_stop));
+        HIP_TRY(hipEventCreate(&g_ev_mid));
+    }
+    HIP_TRY(hipEventRecord(g_ev_start, stream));   // the per-frame prepasses count as binning time
     HIP_TRY(crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, scene->d_rec, stream));
 
     // public variant numbering (crt_set_kernel_variant): 0 auto, 1 brute force, 2 tiled,
@@ -540,6 +607,8 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         cam_ok = cam_ok && std::isfinite(camera->lower_left_corner[k]) && std::isfinite(camera->horizontal[k]) &&
                  std::isfinite(camera->vertical[k]) && std::isfinite(camera->origin[k]) &&
                  fabsf(camera->origin[k]) <= 274877906944.0f && fabsf(camera->lower_left_corner[k]) <= 274877906944.0f;
+    float pos_du = 0.0f, pos_dv = 0.0f, k_slack = 0.0f;
+    cam_ok = cam_ok && camera_slacks(camera, &pos_du, &pos_dv, &k_slack);
     const bool tiled_ok = scene->tiled_safe && cam_ok && scene->n_tris > 0;
     int kernel_variant = 0;
     if (g_variant == 0 || g_variant == 2) kernel_variant = tiled_ok ? 1 : 0;
@@ -559,18 +628,13 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     p.rng_count = count;
     p.inv_nx = 1.0 / (double)(float)nx;
     p.inv_ny = 1.0 / (double)(float)ny;
+    p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
 
-    if (!g_ev_start) {
-        HIP_TRY(hipEventCreate(&g_ev_start));
-        HIP_TRY(hipEventCreate(&g_ev_stop));
-        HIP_TRY(hipEventCreate(&g_ev_mid));
-    }
     if (kernel_variant != 0) {
         int rc = ensure_workspace(nx, row_count);
         if (rc != CRT_OK) return rc;
-        HIP_TRY(crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p.cam, scene->d_cls, stream));
+        HIP_TRY(crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p, scene->d_cls, stream));
     }
-    HIP_TRY(hipEventRecord(g_ev_start, stream));
     HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
                                d_rgb, kernel_variant, kernel_variant ? &g_ws.w : nullptr, g_ws.n_cus,
                                scene->tiled_safe && cam_ok, g_d_stats, kernel_variant ? g_ev_mid : nullptr, stream));
@@ -587,7 +651,8 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     if (!scene || !camera || !out4 || nx <= 0 || ny <= 0 || samples < 0)
         return fail(CRT_ERR_INVALID, "crt_debug_audit_tiles: bad argument");
     if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_debug_audit_tiles: no HIP device");
-    if (!scene->tiled_safe || scene->n_tris <= 0)
+    float pos_du = 0.0f, pos_dv = 0.0f, k_slack = 0.0f;
+    if (!scene->tiled_safe || scene->n_tris <= 0 || !camera_slacks(camera, &pos_du, &pos_dv, &k_slack))
         return fail(CRT_ERR_UNSUPPORTED, "crt_debug_audit_tiles: the scene is not eligible for the tiled kernels");
     crt_rng* rng = crt_rng_create(0, (int64_t)nx * ny, seed);
     if (!rng) return CRT_ERR_HIP;
@@ -604,12 +669,13 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     p.rng_count = (long long)nx * ny;
     p.inv_nx = 1.0 / (double)(float)nx;
     p.inv_ny = 1.0 / (double)(float)ny;
+    p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
     unsigned long long* d = nullptr;
     int rc = ensure_workspace(nx, ny);
     hipError_t e = (rc == CRT_OK) ? hipMalloc(&d, 4 * sizeof(unsigned long long)) : hipErrorUnknown;
     if (e == hipSuccess) e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
     if (e == hipSuccess) e = crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, scene->d_rec, nullptr);
-    if (e == hipSuccess) e = crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p.cam, scene->d_cls, nullptr);
+    if (e == hipSuccess) e = crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p, scene->d_cls, nullptr);
     if (e == hipSuccess) e = crt::launch_audit(p, scene->d_rec, scene->d_cls, scene->n_pad, rng->d_state, &g_ws.w, d, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     unsigned long long h[4] = {0, 0, 0, 0};

@@ -34,7 +34,7 @@ constexpr int kRecFloats = 16;
 // F(u,v) = A + u*B + v*C is the exact value of the form on the un-normalised camera
 // direction d0(u,v) = (llc - o) + u*horizontal + v*vertical; M bounds |G|_1-type magnitudes
 // used for the rounding slack.
-constexpr int kClsPlanes = 4;
+constexpr int kClsPlanes = 5;
 
 // EPSILON of both Triangle ctors the scene pack can reach (shapes/triangle.h:9,22).
 constexpr float kTriEpsilon = 0.000001f;
@@ -55,6 +55,8 @@ struct RenderParams {
     int n_tris;
     long long rng_count;         // number of states = row_count * nx (SoA stride); element = ly * nx + x
     double inv_nx, inv_ny;       // 1.0 / double(float(nx)), 1.0 / double(float(ny)) (host, correctly rounded)
+    float pos_du, pos_dv;        // tiled variant: position slack of the camera in (u,v) (host, camera_slacks)
+    float K_slack;               // tiled variant: slack factor of the form values, whole screen (host, camera_slacks)
 };
 
 __host__ __device__ inline int global_row(int row_begin, int strip_rows, int strip_step, int ly) {
@@ -74,7 +76,7 @@ hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long c
                            int strip_step, uint64_t seed, const uint32_t* d_jump, hipStream_t stream);
 hipError_t launch_tri_prepass(const float* d_base, int n_tris, const float origin[3],
                               float* d_rec, hipStream_t stream);
-hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const CameraPOD& cam,
+hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const RenderParams& p,
                               float4* d_cls, hipStream_t stream);
 // variant 0: brute force (every ray x every triangle); 1: tiled (conservative region/tile
 // classification + exact test on survivors); 2: tiled with tiny list capacities (tests the
@@ -89,6 +91,7 @@ struct TiledWork {
     uint32_t* queue;                 // kClasses weight classes x tiles_total tile ids
     uint32_t* counters;              // kCtrQueueLen+c: queue length, kCtrCursor+c: consumer cursor
     int tiles_x, tiles_y, tiles_total;
+    uint32_t* tile_count;            // per tile: survivors (count pass), fill cursor (fill pass)
 };
 // Weight classes of a tile (by survivor count; heaviest first = longest-processing-time-first
 // order for the persistent shading blocks): class c < kHeavyClasses holds tiles with more than

@@ -305,7 +305,9 @@ __device__ __forceinline__ void exact_test(const Rec16& rc, int i_raw, V3 d, flo
 
     float t = f * tq;                                                 // triangle.h:92
     // hit(...) && tmp_rec.t < closest_so_far                         hitable_list.h:84
-    if (__builtin_amdgcn_inverse_ballot_w64(alive) && t < closest) {
+    // The reference walks in index order with a strict <, i.e. it keeps the smallest t and, among
+    // equal t, the lowest index.  Written order-independently (tile lists are unordered):
+    if (__builtin_amdgcn_inverse_ballot_w64(alive) && (t < closest || (t == closest && i < hit_idx))) {
         closest = t;
         hit_idx = i;
     }
@@ -398,7 +400,7 @@ __device__ __forceinline__ void exact_test_vec(const RecV& rc, int i_raw, V3 d, 
     alive &= __builtin_amdgcn_ballot_w64(!(v < 0.0f)) & __builtin_amdgcn_ballot_w64(!(u + v > 1.0f));   // triangle.h:89
     if (alive == 0ull) return;
     float t = f * tq;                                                 // triangle.h:92
-    if (__builtin_amdgcn_inverse_ballot_w64(alive) && t < closest) {  // hitable_list.h:84
+    if (__builtin_amdgcn_inverse_ballot_w64(alive) && (t < closest || (t == closest && i < hit_idx))) {  // hitable_list.h:84, order-independent
         closest = t;
         hit_idx = i;
     }
@@ -540,310 +542,287 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
 // stores the exact affine coefficients per triangle (computed in fp64); a rectangle is
 // classified with interval bounds of those forms plus a slack that covers every rounding
 // the reference's float evaluation can commit (DESIGN.md §4.4 has the derivation).
-//   phase A  (lane = triangle, 1024 threads): stream all classification records once per
-//            32x32 region, coalesced; survivors -> ordered LDS list.
-//   phase A2 (lane = list entry, per wave):   re-classify against the wave's own 8x8 tile.
-//   phase B  (lane = pixel):                  the reference arithmetic (exact_test) on the
-//            tile's survivors only, in ascending index order.
-constexpr int kRegionW = 128;  // region = 128 x 32 pixels = 16 x 4 tiles: wide, so that strips stay 32 rows
-constexpr int kRegionH = 32;
-constexpr int kRegionTilesX = kRegionW / 8, kRegionTiles = (kRegionW / 8) * (kRegionH / 8);
-constexpr int kTiledThreads = 1024;
-constexpr int kTiledWaves = kTiledThreads / 64;
-constexpr int kK1Max = 14336;  // region list capacity (indices); sized so that two blocks fit the 160 KB LDS
+//   binning (lane = triangle) -> per-tile survivor lists; shading (lane = pixel) -> the reference
+//   arithmetic (exact_test) on the tile's survivors only.
 constexpr int kHeavyMin = 64;  // tiles with more survivors than this are traced by all 16 waves together (measured optimum, 16..128 swept)
 constexpr unsigned kNoList = 0xffffffffu;   // tile_desc.y: the pool was full, walk every triangle
 constexpr unsigned kCullSureBit = 0x80000000u;   // pool entry flag: the cull test cannot reject in this tile
 
-struct TileBox {
-    float uc, hu, vc, hv;   // centre / half extent of the rectangle in (u,v)
-    float K;                // slack factor: kappa * max|d0|
+// ---- binning, triangle-major (lane = triangle).  Two regular grids over this launch's rows:
+// regions (128 x 32 pixels = 16 x 4 tiles; wide, so that multi-GPU strips stay 32 rows) and
+// 8 x 8 tiles.  A cell of pixel columns [x_lo,x_hi) has u = fl((x + U)/nx) with fl(x + U) in
+// [x_lo, x_hi], i.e. u within 6e-8 of [x_lo/nx, x_hi/nx]; the binning uses the interval
+//      centre = fl((x_lo + w/2) * fl(1/nx)),  half = (w/2) fl(1/nx) * 1.00001 + 4e-7 + pos_du
+// which contains it (centre is within 1.2e-7 of the true midpoint) widened by the camera's
+// position slack (RenderParams::pos_du); likewise v from global rows.  Cells are
+// pure arithmetic on wave-uniform integers: no tables, no loads in the loops.
+//   bin_tri_kernel<0>   : ONE coalesced pass over the classification records per screen slice;
+//                         regions are selected by the triangle's (u,v) bounding box alone,
+//                         tiles by box and by the five affine forms; wave votes keep the
+//                         control flow uniform; counts per tile
+//   bin_alloc_kernel    : pool space per tile, descriptors, work queues
+//   bin_tri_kernel<1>   : same walk, writes the triangle index (+ cull-sure bit) into the
+//                         tile's list.  Lists are unordered; the exact test breaks ties by index.
+// The centre value of a form on a tile is F(uc[col], vc[row]) = (A + vc[row]*C) + uc[col]*B:
+// one FMA per form and tile once the row part is known.
+constexpr int kRegionW = 128, kRegionH = 32;
+constexpr int kRegionTilesX = kRegionW / 8, kRegionTilesY = kRegionH / 8;
+constexpr int kBinThreads = 64;
+constexpr int kBinWavesMin = 4096;   // the screen is cut into slices of region rows (blockIdx.y) / columns (blockIdx.z)
+                                     // until the launch has this many wavefronts: few large triangles are not one wave's work
+constexpr int kFewTriangles = 16;    // a region with at most this many candidates is classified lane = tile
+
+struct FormSet {          // the five affine forms of one triangle (dn, a, su, dq, w = a - su - dq)
+    float A[5], B[5], C[5], M[5];
 };
 
-// Bounds for the rays of pixels [x_lo,x_hi) x [y_lo,y_hi) (global pixel coordinates as
-// floats): u = fl((x + U)/nx) with fl(x + U) in [x_lo, x_hi], likewise v.
-__device__ __forceinline__ TileBox make_box(const CameraPOD& c, float x_lo, float x_hi, float y_lo,
-                                            float y_hi, float fnx, float fny) {
-    float u0 = x_lo / fnx, u1 = x_hi / fnx, v0 = y_lo / fny, v1 = y_hi / fny;
-    TileBox b;
-    b.uc = 0.5f * (u0 + u1);
-    b.vc = 0.5f * (v0 + v1);
-    b.hu = (u1 - u0) * 0.5f * 1.00001f + 1.0e-7f;
-    b.hv = (v1 - v0) * 0.5f * 1.00001f + 1.0e-7f;
-    // d0 is monotone in u and in v per component (every rounded operation is monotone), so
-    // its component ranges over the rectangle are attained at the four corners.
-    V3 c00 = camera_direction(c, u0, v0), c10 = camera_direction(c, u1, v0);
-    V3 c01 = camera_direction(c, u0, v1), c11 = camera_direction(c, u1, v1);
-    float lo[3] = {fminf(fminf(c00.x, c10.x), fminf(c01.x, c11.x)), fminf(fminf(c00.y, c10.y), fminf(c01.y, c11.y)),
-                   fminf(fminf(c00.z, c10.z), fminf(c01.z, c11.z))};
-    float hi[3] = {fmaxf(fmaxf(c00.x, c10.x), fmaxf(c01.x, c11.x)), fmaxf(fmaxf(c00.y, c10.y), fmaxf(c01.y, c11.y)),
-                   fmaxf(fmaxf(c00.z, c10.z), fmaxf(c01.z, c11.z))};
-    float s_hi = 0.0f, s_lo = 0.0f, mag = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float mx = fmaxf(fabsf(lo[k]), fabsf(hi[k]));
-        float mn = (lo[k] <= 0.0f && hi[k] >= 0.0f) ? 0.0f : fminf(fabsf(lo[k]), fabsf(hi[k]));
-        s_hi += mx * mx;
-        s_lo += mn * mn;
-        mag = fmaxf(mag, fabsf(c.llc[k]) + fabsf(c.horizontal[k]) + fabsf(c.vertical[k]) + fabsf(c.origin[k]));
-    }
-    float len_hi = sqrtf(s_hi) * 1.000001f;   // >= |d0| of every ray of the rectangle
-    float len_lo = sqrtf(s_lo) * 0.999999f;   // <= |d0|
-    float delta0 = mag * 4.76837158e-7f;      // 2^-21 * mag: abs. error of a d0 component vs the affine model
-    float kappa = 2.0f * (delta0 / len_lo) + 3.0517578125e-5f;   // 2*eta0 + 2^-15  (len_lo == 0 -> inf -> keep all)
-    b.K = kappa * len_hi * 1.001f;
-    return b;
+__device__ __forceinline__ FormSet load_forms(const float4* __restrict__ cls, int n_pad, int idx) {
+    const float4 p0 = cls[(size_t)0 * n_pad + idx], p1 = cls[(size_t)1 * n_pad + idx];
+    const float4 p2 = cls[(size_t)2 * n_pad + idx], p3 = cls[(size_t)3 * n_pad + idx];
+    FormSet f;
+    f.A[0] = p0.x; f.B[0] = p0.y; f.C[0] = p0.z; f.M[0] = p0.w;
+    f.A[1] = p1.x; f.B[1] = p1.y; f.C[1] = p1.z; f.M[1] = p1.w;
+    f.A[2] = p2.x; f.B[2] = p2.y; f.C[2] = p2.z; f.M[2] = p2.w;
+    f.A[3] = p3.x; f.B[3] = p3.y; f.C[3] = p3.z; f.M[3] = p3.w;
+    // third barycentric numerator w = a - su - dq, as its own affine form (tight radius)
+    f.A[4] = p1.x - p2.x - p3.x; f.B[4] = p1.y - p2.y - p3.y; f.C[4] = p1.z - p2.z - p3.z;
+    f.M[4] = p2.w + p3.w + 1.25f * p1.w;
+    return f;
 }
 
-// true = some ray of the rectangle may pass Triangle::collision_detection for this triangle
-// (NaN anywhere -> true).  p0..p3 are the four planes of the classification record.
-// *cull_sure (optional): every ray of the rectangle certainly has dn >= 0, i.e. the reference's
-// first test `dot(d, normal) < 0` cannot reject — the shading kernel then skips it.
-__device__ __forceinline__ bool may_hit(float4 p0, float4 p1, float4 p2, float4 p3, const TileBox& b,
-                                        bool* cull_sure = nullptr) {
-    // centre value and radius of each form over the rectangle
-    float c_dn = __builtin_fmaf(b.vc, p0.z, __builtin_fmaf(b.uc, p0.y, p0.x));
-    float r_dn = __builtin_fmaf(b.hv, fabsf(p0.z), b.hu * fabsf(p0.y));
-    float c_a = __builtin_fmaf(b.vc, p1.z, __builtin_fmaf(b.uc, p1.y, p1.x));
-    float r_a = __builtin_fmaf(b.hv, fabsf(p1.z), b.hu * fabsf(p1.y));
-    float c_su = __builtin_fmaf(b.vc, p2.z, __builtin_fmaf(b.uc, p2.y, p2.x));
-    float r_su = __builtin_fmaf(b.hv, fabsf(p2.z), b.hu * fabsf(p2.y));
-    float c_dq = __builtin_fmaf(b.vc, p3.z, __builtin_fmaf(b.uc, p3.y, p3.x));
-    float r_dq = __builtin_fmaf(b.hv, fabsf(p3.z), b.hu * fabsf(p3.y));
-    // third barycentric numerator w = a - su - dq, as its own affine form (tight radius)
-    float Aw = p1.x - p2.x - p3.x, Bw = p1.y - p2.y - p3.y, Cw = p1.z - p2.z - p3.z;
-    float c_w = __builtin_fmaf(b.vc, Cw, __builtin_fmaf(b.uc, Bw, Aw));
-    float r_w = __builtin_fmaf(b.hv, fabsf(Cw), b.hu * fabsf(Bw));
-    // slacks (un-normalised units): K * M
-    float S_dn = b.K * p0.w, S_a = b.K * p1.w, S_su = b.K * p2.w, S_dq = b.K * p3.w;
-    float S_w = b.K * (p2.w + p3.w + 1.25f * p1.w);
-    // relative inflation of the radii covers the rounding of this very evaluation
-    r_dn = r_dn * 1.0001f; r_a = r_a * 1.0001f; r_su = r_su * 1.0001f; r_dq = r_dq * 1.0001f; r_w = r_w * 1.0001f;
-
-    bool cull_ok = !(c_dn + r_dn < -S_dn);                 // some ray may have dn >= 0
-    if (cull_sure) *cull_sure = (c_dn - r_dn > S_dn);      // dn_float >= lambda*(c-r) - kappa*M > 0 for every ray
-    bool pos = !(c_a + r_a < -S_a) && !(c_su + r_su < -S_su) && !(c_dq + r_dq < -S_dq) && !(c_w + r_w < -S_w);
-    bool neg = !(c_a - r_a > S_a) && !(c_su - r_su > S_su) && !(c_dq - r_dq > S_dq) && !(c_w - r_w > S_w);
+// some ray of the cell may pass Triangle::collision_detection (NaN anywhere -> true).
+// c[] = centre values, q[] = radius*1.0001 + K*M of the five forms.
+__device__ __forceinline__ bool cell_may_hit(const float c[5], const float q[5]) {
+    const bool cull_ok = !(c[0] < -q[0]);                                   // some ray may have dn >= 0
+    const bool pos = !(c[1] < -q[1]) && !(c[2] < -q[2]) && !(c[3] < -q[3]) && !(c[4] < -q[4]);
+    const bool neg = !(c[1] > q[1]) && !(c[2] > q[2]) && !(c[3] > q[3]) && !(c[4] > q[4]);
     return cull_ok && (pos || neg);
 }
 
-__device__ __forceinline__ bool classify(const float4* __restrict__ cls, int n_pad, int idx, const TileBox& b) {
-    float4 p0 = cls[(size_t)0 * n_pad + idx];
-    float4 p1 = cls[(size_t)1 * n_pad + idx];
-    float4 p2 = cls[(size_t)2 * n_pad + idx];
-    float4 p3 = cls[(size_t)3 * n_pad + idx];
-    return may_hit(p0, p1, p2, p3, b);
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
-// ---- kernel 1 of the tiled variant: binning.  One 1024-thread block per 32x32 region.
-// Output: for every 8x8 tile of the band its survivor list (ascending triangle indices) in
-// a global pool, a descriptor {offset, count}, and its id appended to one of four work
-// queues by weight class.
-__global__ void __launch_bounds__(kTiledThreads, 8)
-bin_tiles_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledWork w, int k1_cap,
-                 int heavy_min, unsigned long long* __restrict__ stats) {
-    __shared__ uint32_t list1[kK1Max];
-    __shared__ int wcnt[kTiledWaves];
-    __shared__ TileBox tbox[kRegionTiles];
-    __shared__ float grid_uc[kRegionTilesX], grid_vc[kRegionH / 8];
-    __shared__ unsigned tile_cnt[kRegionTiles], tile_base[kRegionTiles];
-    __shared__ int tile_ok[kRegionTiles];
-    __shared__ unsigned long long wmask[kTiledWaves][kRegionTiles], wsure[kTiledWaves][kRegionTiles];
-    __shared__ int region_fits;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_tris = p.n_tris;
-    const float fnx = (float)p.nx, fny = (float)p.ny;
+// FILL 0: count the survivors of every tile.  FILL 1 (after bin_alloc_kernel): write them.
+// Control flow is wave-uniform (ballots), so every tile costs one atomic per wavefront that
+// touches it.
+template <int FILL>
+__global__ void __launch_bounds__(kBinThreads)
+bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledWork w,
+               unsigned long long* __restrict__ stats) {
+    unsigned n_region_hit = 0, n_tile_box = 0, n_tile_hit = 0;   // diagnostics (wave-uniform)
+    const long long clk0 = stats ? (long long)clock64() : 0;
+    const int tri = blockIdx.x * kBinThreads + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const unsigned long long lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const bool have = tri < p.n_tris;
+    const int region_nx = (w.tiles_x + kRegionTilesX - 1) / kRegionTilesX;
+    const int region_ny = (w.tiles_y + kRegionTilesY - 1) / kRegionTilesY;
+    const int rows_per_slice = (region_ny + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int ry_begin = (int)blockIdx.y * rows_per_slice, ry_end = min(ry_begin + rows_per_slice, region_ny);
+    const int cols_per_slice = (region_nx + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int rx_begin = (int)blockIdx.z * cols_per_slice, rx_end = min(rx_begin + cols_per_slice, region_nx);
 
-    // region = 128x32 pixels: 32 local rows (never straddles a strip: strip_rows % 32 == 0 or
-    // strip_step == 1); ry* are global image rows
-    const int rx0 = blockIdx.x * kRegionW;
-    const int rly0 = blockIdx.y * kRegionH;
-    const int ry0 = global_row(p.row_begin, p.strip_rows, p.strip_step, rly0);
-    const int rx1 = min(rx0 + kRegionW, p.nx);
-    const int ry1 = ry0 + min(kRegionH, p.row_count - rly0);
-
-    const long long bclk0 = stats ? (long long)clock64() : 0;
-    // ---- phase A: all classification records against the region rectangle
-    TileBox rb = make_box(p.cam, (float)rx0, (float)rx1, (float)ry0, (float)ry1, fnx, fny);
-    int cnt1 = 0;
-    for (int base = 0; base < n_tris; base += kTiledThreads) {
-        const int t = base + tid;
-        bool s = (t < n_tris) && classify(cls, n_pad, t, rb);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
-        if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
-        __syncthreads();
-        int before = 0, total = 0;
+    const float rnx = 1.0f / (float)p.nx, rny = 1.0f / (float)p.ny;
+    const float hu_t = (4.0f * rnx) * 1.00001f + 4.0e-7f + p.pos_du, hv_t = (4.0f * rny) * 1.00001f + 4.0e-7f + p.pos_dv;
+    const float hu_r = (0.5f * kRegionW * rnx) * 1.00001f + 4.0e-7f + p.pos_du;
+    const float hv_r = (0.5f * kRegionH * rny) * 1.00001f + 4.0e-7f + p.pos_dv;
+    // bounding box (u_lo, u_hi, v_lo, v_hi) of the triangle; box tests as "cell centre within
+    // [lo - half, hi + half]", written so that NaN keeps the triangle
+    const float4 bb = cls[(size_t)4 * n_pad + (have ? tri : 0)];
+    const float rv_lo = bb.z - hv_r, rv_hi = bb.w + hv_r;
+    // slice test first: most wavefronts of a slice have nothing to do in it
+    {
+        const float v_first = (float)global_row(p.row_begin, p.strip_rows, p.strip_step, ry_begin * kRegionH) * rny;
+        const int ly_last = min(ry_end * kRegionH, p.row_count) - 1;
+        const float v_last = (float)(global_row(p.row_begin, p.strip_rows, p.strip_step, max(ly_last, 0)) + 1) * rny;
+        const float u_first = (float)(rx_begin * kRegionW) * rnx, u_last = (float)(rx_end * kRegionW) * rnx;
+        const bool in_slice = have && ry_begin < ry_end && rx_begin < rx_end && !(bb.w < v_first - hv_t) &&
+                              !(bb.z > v_last + hv_t) && !(bb.y < u_first - hu_t) && !(bb.x > u_last + hu_t);
+        if (__builtin_amdgcn_ballot_w64(in_slice) == 0ull) return;
+    }
+    const float ru_lo = bb.x - hu_r, ru_hi = bb.y + hu_r;
+    const float tu_lo = bb.x - hu_t, tu_hi = bb.y + hu_t, tv_lo = bb.z - hv_t, tv_hi = bb.w + hv_t;
+    const FormSet f = load_forms(cls, n_pad, have ? tri : 0);   // coalesced: 1 KiB per plane and wavefront
+    float qt[5], qr[5];   // radius * 1.0001 + K * M on a tile / on a region
 #pragma unroll
-        for (int k = 0; k < kTiledWaves; ++k) {
-            int cw = wcnt[k];
-            before += (k < wave) ? cw : 0;
-            total += cw;
-        }
-        if (s) {
-            int pos = cnt1 + before + __builtin_popcountll(m & lanemask_lt);
-            if (pos < k1_cap) list1[pos] = (uint32_t)t;
-        }
-        cnt1 += total;
-        __syncthreads();
+    for (int k = 0; k < 5; ++k) {
+        qt[k] = __builtin_fmaf(p.K_slack, f.M[k], __builtin_fmaf(hv_t, fabsf(f.C[k]), hu_t * fabsf(f.B[k])) * 1.0001f);
+        qr[k] = __builtin_fmaf(p.K_slack, f.M[k], __builtin_fmaf(hv_r, fabsf(f.C[k]), hu_r * fabsf(f.B[k])) * 1.0001f);
     }
-    const bool overflow1 = cnt1 > k1_cap;   // block-uniform: region list truncated -> re-scan everything
-    if (stats && tid == 0) {                // diagnostics only (crt_debug_tiled_stats)
-        atomicAdd(&stats[0], 1ull);
-        atomicAdd(&stats[1], (unsigned long long)cnt1);
-        atomicMax(&stats[2], (unsigned long long)cnt1);
-        atomicAdd(&stats[3], overflow1 ? 1ull : 0ull);
-    }
-
-    const long long bclk1 = stats ? (long long)clock64() : 0;
-    // ---- phase A2, lane = region-list entry: every thread loads the record of ONE entry and
-    // classifies it against all 64 tile rectangles of the region (boxes in LDS).  Pass 0
-    // counts per tile, one atomicAdd reserves the region's pool space, pass 1 classifies again
-    // and scatters the indices tile by tile in list order.
-    const int src_count = overflow1 ? n_tris : cnt1;
-    if (tid < kRegionTiles) {
-        const int tx = blockIdx.x * kRegionTilesX + (tid % kRegionTilesX);
-        const int tyl = blockIdx.y * (kRegionH / 8) + (tid / kRegionTilesX);
-        const bool valid = tx < w.tiles_x && tyl < w.tiles_y;
-        const int tx0 = tx * 8, ty0 = ry0 + (tid / kRegionTilesX) * 8;
-        const int tx1 = min(tx0 + 8, rx1), ty1 = min(ty0 + 8, ry1);
-        tbox[tid] = make_box(p.cam, (float)tx0, (float)(valid ? tx1 : tx0 + 8), (float)ty0, (float)(valid ? ty1 : ty0 + 8), fnx, fny);
-        tile_ok[tid] = valid ? 1 : 0;
-        tile_cnt[tid] = 0;
-    }
-    __syncthreads();
-    if (tid < kRegionTilesX) grid_uc[tid] = tbox[tid].uc;
-    if (tid < kRegionH / 8) grid_vc[tid] = tbox[tid * kRegionTilesX].vc;
-    float grid_hu = 0.0f, grid_hv = 0.0f;
-    for (int t = 0; t < kRegionTiles; ++t) {
-        grid_hu = fmaxf(grid_hu, tbox[t].hu);
-        grid_hv = fmaxf(grid_hv, tbox[t].hv);
-    }
-    __syncthreads();
-    for (int pass = 0; pass < 2; ++pass) {
-        int run[kRegionTiles / kTiledWaves] = {0, 0, 0, 0};   // pass 1: entries already written for this wave's tiles
-        for (int base = 0; base < src_count; base += kTiledThreads) {
-            const int k = base + tid;
-            const bool have = k < src_count;
-            const int idx = have ? (overflow1 ? k : (int)list1[k]) : 0;
-            const float4 p0 = cls[(size_t)0 * n_pad + idx], p1 = cls[(size_t)1 * n_pad + idx];
-            const float4 p2 = cls[(size_t)2 * n_pad + idx], p3 = cls[(size_t)3 * n_pad + idx];
-            // The 64 tile rectangles form a regular 16 x 4 grid, so the centre value of a form
-            // is rowpart[row] + uc[col] * B: one FMA per form and tile.  Radii use the largest
-            // tile half-extents and the slack factor of the whole region (both >= the per-tile
-            // values of make_box/may_hit, so this test keeps at least what may_hit keeps).
-            const float Aw = p1.x - p2.x - p3.x, Bw = p1.y - p2.y - p3.y, Cw = p1.z - p2.z - p3.z;
-            const float q_dn = (__builtin_fmaf(grid_hv, fabsf(p0.z), grid_hu * fabsf(p0.y)) * 1.0001f) + rb.K * p0.w;
-            const float q_a = (__builtin_fmaf(grid_hv, fabsf(p1.z), grid_hu * fabsf(p1.y)) * 1.0001f) + rb.K * p1.w;
-            const float q_su = (__builtin_fmaf(grid_hv, fabsf(p2.z), grid_hu * fabsf(p2.y)) * 1.0001f) + rb.K * p2.w;
-            const float q_dq = (__builtin_fmaf(grid_hv, fabsf(p3.z), grid_hu * fabsf(p3.y)) * 1.0001f) + rb.K * p3.w;
-            const float q_w = (__builtin_fmaf(grid_hv, fabsf(Cw), grid_hu * fabsf(Bw)) * 1.0001f) +
-                              rb.K * (p2.w + p3.w + 1.25f * p1.w);
-            // sure: c_dn - r_dn > S_dn with the same r, S  <=>  c_dn > q_dn
-            for (int row = 0; row < kRegionH / 8; ++row) {
-                const float vc = grid_vc[row];
-                const float r_dn = __builtin_fmaf(vc, p0.z, p0.x), r_a = __builtin_fmaf(vc, p1.z, p1.x);
-                const float r_su = __builtin_fmaf(vc, p2.z, p2.x), r_dq = __builtin_fmaf(vc, p3.z, p3.x);
-                const float r_w = __builtin_fmaf(vc, Cw, Aw);
-                for (int col = 0; col < kRegionTilesX; ++col) {
-                    const int t = row * kRegionTilesX + col;
-                    const float uc = grid_uc[col];
-                    const float c_dn = __builtin_fmaf(uc, p0.y, r_dn), c_a = __builtin_fmaf(uc, p1.y, r_a);
-                    const float c_su = __builtin_fmaf(uc, p2.y, r_su), c_dq = __builtin_fmaf(uc, p3.y, r_dq);
-                    const float c_w = __builtin_fmaf(uc, Bw, r_w);
-                    const bool cull_ok = !(c_dn < -q_dn);
-                    const bool pos = !(c_a < -q_a) && !(c_su < -q_su) && !(c_dq < -q_dq) && !(c_w < -q_w);
-                    const bool neg = !(c_a > q_a) && !(c_su > q_su) && !(c_dq > q_dq) && !(c_w > q_w);
-                    const bool s = have && cull_ok && (pos || neg);
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
-                    if (pass == 0) {
-                        if (lane == 0 && m != 0ull) atomicAdd(&tile_cnt[t], (unsigned)__builtin_popcountll(m));
+    float c[5];
+    for (int ry = ry_begin; ry < ry_end; ++ry) {
+        // 32 local rows: inside one strip, so the region's global rows are contiguous
+        const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ry * kRegionH);
+        const float vcr = (float)(gy + kRegionH / 2) * rny;
+        const bool in_row = have && !(vcr < rv_lo) && !(vcr > rv_hi);
+        if (__builtin_amdgcn_ballot_w64(in_row) == 0ull) continue;
+        float row1[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) row1[k] = __builtin_fmaf(vcr, f.C[k], f.A[k]);
+        for (int rx = rx_begin; rx < rx_end; ++rx) {
+            const float ucr = (float)(rx * kRegionW + kRegionW / 2) * rnx;
+            const bool s1_box = in_row && !(ucr < ru_lo) && !(ucr > ru_hi);
+            if (__builtin_amdgcn_ballot_w64(s1_box) == 0ull) continue;
+            // the forms on the whole region: drops the regions a long thin box only passes by
+#pragma unroll
+            for (int k = 0; k < 5; ++k) c[k] = __builtin_fmaf(ucr, f.B[k], row1[k]);
+            const bool s1 = s1_box && cell_may_hit(c, qr);
+            const unsigned long long m1 = __builtin_amdgcn_ballot_w64(s1);
+            if (m1 == 0ull) continue;
+            ++n_region_hit;
+            if (__builtin_popcountll(m1) <= kFewTriangles) {
+                // few candidates: lane = tile of the region (16 x 4), one triangle at a time,
+                // broadcast from its lane.  Same arithmetic as below, so both passes and both
+                // modes select the same (tile, triangle) pairs.
+                const int tx = rx * kRegionTilesX + (lane & (kRegionTilesX - 1)), lty = lane / kRegionTilesX;
+                const int ty = ry * kRegionTilesY + lty;
+                const bool tile_ok = tx < w.tiles_x && ty < w.tiles_y;
+                const int tile = ty * w.tiles_x + tx;
+                const float uct = (float)(tx * 8 + 4) * rnx, vct = (float)(gy + lty * 8 + 4) * rny;
+                uint2 desc = make_uint2(0u, kNoList);
+                if (FILL != 0 && tile_ok) desc = w.tile_desc[tile];
+                for (unsigned long long mm = m1; mm != 0ull; mm &= mm - 1ull) {
+                    const int src = (int)__builtin_ctzll(mm);
+                    float q5[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        c[k] = __builtin_fmaf(uct, lane_bcast(f.B[k], src), __builtin_fmaf(vct, lane_bcast(f.C[k], src), lane_bcast(f.A[k], src)));
+                        q5[k] = lane_bcast(qt[k], src);
+                    }
+                    const bool s2 = tile_ok && !(vct < lane_bcast(tv_lo, src)) && !(vct > lane_bcast(tv_hi, src)) &&
+                                    !(uct < lane_bcast(tu_lo, src)) && !(uct > lane_bcast(tu_hi, src)) && cell_may_hit(c, q5);
+                    n_tile_box += 64u;
+                    if (s2) {
+                        const unsigned tri_src = (unsigned)(blockIdx.x * kBinThreads + src);
+                        if (FILL == 0) {
+                            atomicAdd(&w.tile_count[tile], 1u);
+                        } else if (desc.y != kNoList) {
+                            const unsigned at = atomicSub(&w.tile_count[tile], 1u) - 1u;
+                            w.pool[(size_t)desc.x + at] = tri_src | ((c[0] > q5[0]) ? kCullSureBit : 0u);
+                        }
+                    }
+                }
+                continue;
+            }
+            const int ty1 = min((ry + 1) * kRegionTilesY, w.tiles_y), tx1 = min((rx + 1) * kRegionTilesX, w.tiles_x);
+            for (int ty = ry * kRegionTilesY; ty < ty1; ++ty) {
+                const float vct = (float)(gy + (ty - ry * kRegionTilesY) * 8 + 4) * rny;
+                const bool s_row = s1 && !(vct < tv_lo) && !(vct > tv_hi);
+                if (__builtin_amdgcn_ballot_w64(s_row) == 0ull) continue;
+                float row2[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) row2[k] = __builtin_fmaf(vct, f.C[k], f.A[k]);
+                for (int tx = rx * kRegionTilesX; tx < tx1; ++tx) {
+                    const float uct = (float)(tx * 8 + 4) * rnx;
+                    const bool s_box = s_row && !(uct < tu_lo) && !(uct > tu_hi);
+                    if (__builtin_amdgcn_ballot_w64(s_box) == 0ull) continue;
+                    ++n_tile_box;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) c[k] = __builtin_fmaf(uct, f.B[k], row2[k]);
+                    const bool s2 = s_box && cell_may_hit(c, qt);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(s2);
+                    if (m == 0ull) continue;
+                    ++n_tile_hit;
+                    const int tile = ty * w.tiles_x + tx;
+                    const unsigned n = (unsigned)__builtin_popcountll(m);
+                    if (FILL == 0) {
+                        if (lane == 0) atomicAdd(&w.tile_count[tile], n);
                     } else {
-                        const unsigned long long ms = __builtin_amdgcn_ballot_w64(s && (c_dn > q_dn));
-                        if (lane == 0) {
-                            wmask[wave][t] = m;
-                            wsure[wave][t] = ms;
-                        }
+                        const uint2 desc = w.tile_desc[tile];
+                        if (desc.y == kNoList) continue;
+                        // the count doubles as the fill cursor: it is back at 0 after this pass
+                        unsigned at = 0;
+                        if (lane == 0) at = atomicSub(&w.tile_count[tile], n) - n;
+                        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+                        // cull-sure: c_dn - r_dn > S_dn with the same r, S  <=>  c_dn > q_dn
+                        if (s2)
+                            w.pool[(size_t)desc.x + at + (unsigned)__builtin_popcountll(m & lanemask_lt)] =
+                                (unsigned)tri | ((c[0] > qt[0]) ? kCullSureBit : 0u);
                     }
                 }
             }
-            if (pass == 1) {
-                __syncthreads();
-                // scatter: this wave owns tiles wave, wave+16, wave+32, wave+48
-#pragma unroll
-                for (int q = 0; q < kRegionTiles / kTiledWaves; ++q) {
-                    const int t = wave + q * kTiledWaves;
-                    if (tile_base[t] == kNoList) continue;
-                    for (int w2 = 0; w2 < kTiledWaves; ++w2) {
-                        const unsigned long long m = wmask[w2][t];
-                        if (m == 0ull) continue;
-                        const unsigned long long ms = wsure[w2][t];
-                        const int k2 = base + w2 * 64 + lane;
-                        if ((m >> lane) & 1ull) {
-                            const unsigned e = (overflow1 ? (unsigned)k2 : list1[k2]) | (((ms >> lane) & 1ull) ? kCullSureBit : 0u);
-                            w.pool[(size_t)tile_base[t] + (unsigned)(run[q] + __builtin_popcountll(m & lanemask_lt))] = e;
-                        }
-                        run[q] += __builtin_popcountll(m);
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        if (pass == 0) {
-            __syncthreads();
-            if (tid == 0) {   // reserve the region's pool space; tiles of a region are contiguous
-                unsigned total = 0;
-                for (int t = 0; t < kRegionTiles; ++t) total += tile_ok[t] ? tile_cnt[t] : 0u;
-                const unsigned long long off = atomicAdd(&w.counters64[0], (unsigned long long)total);
-                const bool fits = off + (unsigned long long)total <= (unsigned long long)w.pool_cap;
-                unsigned at = (unsigned)off;
-                for (int t = 0; t < kRegionTiles; ++t) {
-                    tile_base[t] = (fits && tile_ok[t]) ? at : kNoList;
-                    at += tile_ok[t] ? tile_cnt[t] : 0u;
-                }
-                region_fits = fits ? 1 : 0;
-            }
-            __syncthreads();
-            if (tid < kRegionTiles && tile_ok[tid]) {
-                const int tx = blockIdx.x * kRegionTilesX + (tid % kRegionTilesX);
-                const int tyl = blockIdx.y * (kRegionH / 8) + (tid / kRegionTilesX);
-                const int tile_id = tyl * w.tiles_x + tx;
-                const unsigned cnt2 = tile_cnt[tid];
-                const bool fits = region_fits != 0;
-                // weight class (heaviest first); the last heavy class starts at heavy_min, below is light
-                const unsigned weight = fits ? cnt2 : 0xffffffffu;
-                const unsigned mins[kHeavyClasses] = {1024u, 768u, 512u, 384u, 256u, 192u, 128u, 96u, (unsigned)heavy_min};
-                int c = kHeavyClasses;
-#pragma unroll
-                for (int q = kHeavyClasses - 1; q >= 0; --q)
-                    if (weight > mins[q] && weight > (unsigned)heavy_min) c = q;
-                w.tile_desc[tile_id] = make_uint2(fits ? tile_base[tid] : 0u, fits ? cnt2 : kNoList);
-                const unsigned pos = atomicAdd(&w.counters[kCtrQueueLen + c], 1u);
-                w.queue[(size_t)c * w.tiles_total + pos] = (uint32_t)tile_id;
-                if (stats) {
-                    atomicAdd(&stats[4], 1ull);
-                    atomicAdd(&stats[5], (unsigned long long)cnt2);
-                    atomicMax(&stats[6], (unsigned long long)cnt2);
-                    atomicAdd(&stats[7], fits ? 0ull : 1ull);
-                    int bucket = 0;
-                    while ((cnt2 >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt2 in [2^(b-1), 2^b)
-                    atomicAdd(&stats[8 + bucket], 1ull);
-                }
-            }
-            if (region_fits == 0) break;   // block-uniform: nothing to write
         }
     }
-    if (stats && lane == 0) {
-        const long long bclk2 = (long long)clock64();
-        if (wave == 0) {
-            atomicAdd(&stats[29], (unsigned long long)(bclk1 - bclk0));   // phase A, per block
-            atomicMax(&stats[30], (unsigned long long)(bclk1 - bclk0));
-        }
-        atomicMax(&stats[31], (unsigned long long)(bclk2 - bclk1));       // phase A2, slowest wave
+    if (FILL == 0 && stats && lane == 0) {   // cells a wavefront walks, per level
+        atomicAdd(&stats[0], 1ull);
+        atomicAdd(&stats[1], (unsigned long long)n_region_hit);
+        atomicAdd(&stats[2], (unsigned long long)n_tile_box);
+        atomicAdd(&stats[3], (unsigned long long)n_tile_hit);
+        atomicMax(&stats[29], (unsigned long long)n_region_hit);     // the busiest wavefront
+        atomicMax(&stats[30], (unsigned long long)n_tile_box);
+        atomicMax(&stats[31], (unsigned long long)(clock64() - clk0));
     }
+}
+
+// lane = tile: reserve the tile's pool space (one atomic per wavefront), descriptor, work queue.
+__global__ void __launch_bounds__(256)
+bin_alloc_kernel(TiledWork w, int heavy_min, unsigned long long* __restrict__ stats) {
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = tile < w.tiles_total;
+    const unsigned cnt = valid ? w.tile_count[tile] : 0u;
+    unsigned incl = cnt;                                   // inclusive scan inside the wavefront
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const unsigned v = __shfl_up(incl, ofs, 64);
+        if (lane >= ofs) incl += v;
+    }
+    const unsigned total = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 0 && total != 0u) base = atomicAdd(&w.counters64[0], (unsigned long long)total);
+    base = __shfl(base, 0, 64);
+    const bool fits = base + total <= (unsigned long long)w.pool_cap;   // per wavefront of tiles
+    if (!valid) return;
+    w.tile_desc[tile] = fits ? make_uint2((unsigned)base + (incl - cnt), cnt) : make_uint2(0u, kNoList);
+    if (!fits) w.tile_count[tile] = 0u;                    // no fill pass for this tile
+    // weight class (heaviest first); the last heavy class starts at heavy_min, below is light
+    const unsigned weight = fits ? cnt : 0xffffffffu;
+    const unsigned mins[kHeavyClasses] = {1024u, 768u, 512u, 384u, 256u, 192u, 128u, 96u, (unsigned)heavy_min};
+    int c = kHeavyClasses;
+#pragma unroll
+    for (int k = kHeavyClasses - 1; k >= 0; --k)
+        if (weight > mins[k] && weight > (unsigned)heavy_min) c = k;
+    // queue push, one atomic per wavefront and class present in it
+    const unsigned long long lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(true);
+    while (todo != 0ull) {
+        const int cc = __builtin_amdgcn_readlane(c, (int)__builtin_ctzll(todo));
+        const unsigned long long mc = __builtin_amdgcn_ballot_w64(c == cc);
+        unsigned qbase = 0;
+        if (lane == (int)__builtin_ctzll(mc)) qbase = atomicAdd(&w.counters[kCtrQueueLen + cc], (unsigned)__builtin_popcountll(mc));
+        qbase = (unsigned)__builtin_amdgcn_readlane((int)qbase, (int)__builtin_ctzll(mc));
+        if (c == cc) w.queue[(size_t)cc * w.tiles_total + qbase + (unsigned)__builtin_popcountll(mc & lanemask_lt)] = (uint32_t)tile;
+        todo &= ~mc;
+    }
+    if (stats) {                                            // diagnostics only (crt_debug_tiled_stats)
+        atomicAdd(&stats[4], 1ull);
+        atomicAdd(&stats[5], (unsigned long long)cnt);
+        atomicMax(&stats[6], (unsigned long long)cnt);
+        atomicAdd(&stats[7], fits ? 0ull : 1ull);
+        int bucket = 0;
+        while ((cnt >> bucket) != 0 && bucket < 15) ++bucket;   // bucket b: cnt in [2^(b-1), 2^b)
+        atomicAdd(&stats[8 + bucket], 1ull);
+    }
+}
+
+// binning of one launch: tables, count, allocate, fill (all on `stream`)
+static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int n_pad, const TiledWork& w,
+                                 int heavy_min, unsigned long long* d_stats, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(w.tile_count, 0, (size_t)w.tiles_total * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int region_nx = (w.tiles_x + kRegionTilesX - 1) / kRegionTilesX, region_ny = (w.tiles_y + kRegionTilesY - 1) / kRegionTilesY;
+    const int n_waves = (p.n_tris + kBinThreads - 1) / kBinThreads;
+    const int slices_y = std::max(1, std::min(region_ny, kBinWavesMin / std::max(n_waves, 1)));
+    const int slices_x = std::max(1, std::min(region_nx, kBinWavesMin / std::max(n_waves * slices_y, 1)));
+    const dim3 grid_tri((unsigned)n_waves, (unsigned)slices_y, (unsigned)slices_x);
+    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<0>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats);
+    hipLaunchKernelGGL(bin_alloc_kernel, dim3((unsigned)((w.tiles_total + 255) / 256)), dim3(256), 0, stream, w,
+                       heavy_min, d_stats);
+    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<1>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats);
+    return hipGetLastError();
 }
 
 // (t, index) as one 64-bit key whose unsigned order is the reference's accept order: smaller t
@@ -1044,10 +1023,11 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
 // Classification prepass: per triangle, the exact (fp64) affine coefficients of the four
 // forms over d0(u,v) = (llc - o) + u*H + v*V, rounded to fp32, and the magnitudes M.
 __global__ void __launch_bounds__(256)
-cls_prepass_kernel(const float* __restrict__ rec, int n, int n_pad, CameraPOD cam,
+cls_prepass_kernel(const float* __restrict__ rec, int n, int n_pad, RenderParams p,
                    float4* __restrict__ cls) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const CameraPOD& cam = p.cam;
     const float* r = rec + (size_t)i * kRecFloats;
     const double nx = r[0], ny = r[1], nz = r[2];
     const double e2x = r[3], e2y = r[4], e2z = r[5];
@@ -1062,27 +1042,92 @@ cls_prepass_kernel(const float* __restrict__ rec, int n, int n_pad, CameraPOD ca
     const double p0z = (double)cam.llc[2] - (double)cam.origin[2];
     const double hx = cam.horizontal[0], hy = cam.horizontal[1], hz = cam.horizontal[2];
     const double vx = cam.vertical[0], vy = cam.vertical[1], vz = cam.vertical[2];
-    auto form = [&](double gx, double gy, double gz, float M) {
-        return make_float4((float)(p0x * gx + p0y * gy + p0z * gz), (float)(hx * gx + hy * gy + hz * gz),
-                           (float)(vx * gx + vy * gy + vz * gz), M);
+    double FA[5], FB[5], FC[5];   // fp64 coefficients of dn, a, su, dq, w
+    auto form = [&](int k, double gx, double gy, double gz) {
+        FA[k] = p0x * gx + p0y * gy + p0z * gz;
+        FB[k] = hx * gx + hy * gy + hz * gz;
+        FC[k] = vx * gx + vy * gy + vz * gz;
     };
+    form(0, nx, ny, nz);
+    form(1, gax, gay, gaz);
+    form(2, gsx, gsy, gsz);
+    form(3, qx, qy, qz);
     const float n1 = fabsf(r[0]) + fabsf(r[1]) + fabsf(r[2]);
     const float e11 = fabsf(r[6]) + fabsf(r[7]) + fabsf(r[8]);
     const float e21 = fabsf(r[3]) + fabsf(r[4]) + fabsf(r[5]);
     const float s1 = fabsf(r[9]) + fabsf(r[10]) + fabsf(r[11]);
     const float q1 = fabsf(r[12]) + fabsf(r[13]) + fabsf(r[14]);
     const float Ma = e11 * e21 * 1.001f;
-    cls[(size_t)0 * n_pad + i] = form(nx, ny, nz, n1 * 1.001f);
-    cls[(size_t)1 * n_pad + i] = form(gax, gay, gaz, Ma);
-    cls[(size_t)2 * n_pad + i] = form(gsx, gsy, gsz, s1 * e21 * 1.001f + Ma * 9.5367431640625e-7f);
-    cls[(size_t)3 * n_pad + i] = form(qx, qy, qz, q1 * 1.001f + Ma * 9.5367431640625e-7f);
+    float M[5] = {n1 * 1.001f, Ma, s1 * e21 * 1.001f + Ma * 9.5367431640625e-7f, q1 * 1.001f + Ma * 9.5367431640625e-7f, 0.0f};
+    float4 rec4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        rec4[k] = make_float4((float)FA[k], (float)FB[k], (float)FC[k], M[k]);
+        cls[(size_t)k * n_pad + i] = rec4[k];
+    }
+    // w exactly as the binning kernel forms it (from the rounded records), so that both tests
+    // bound the same function
+    FA[4] = (double)(rec4[1].x - rec4[2].x - rec4[3].x);
+    FB[4] = (double)(rec4[1].y - rec4[2].y - rec4[3].y);
+    FC[4] = (double)(rec4[1].z - rec4[2].z - rec4[3].z);
+    M[4] = M[2] + M[3] + 1.25f * M[1];
+
+    // Bounding box in (u,v) of every model position whose ray may be accepted: the screen
+    // rectangle (widened by the position slack) clipped by the relaxed predicates
+    //   dn >= -S_dn  and  [ a, su, dq, w >= -S   or   a, su, dq, w <= +S ],   S_X = K * M_X,
+    // each a half-plane of the (u,v) plane.  fp64 Sutherland-Hodgman; the slacks are taken 1 %
+    // larger and the box 2e-6 wider than computed, which covers the fp64 rounding by far.
+    bool finite_all = true;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) finite_all = finite_all && isfinite(FA[k]) && isfinite(FB[k]) && isfinite(FC[k]) && isfinite(M[k]);
+    const double pad_u = (double)p.pos_du + 1.0e-6, pad_v = (double)p.pos_dv + 1.0e-6;
+    double bu_lo = 1.0e30, bu_hi = -1.0e30, bv_lo = 1.0e30, bv_hi = -1.0e30;
+    if (!finite_all) {
+        bu_lo = -pad_u; bu_hi = 1.0 + pad_u; bv_lo = -pad_v; bv_hi = 1.0 + pad_v;
+    } else {
+        for (int side = 0; side < 2; ++side) {
+            double px[16], py[16], ox[16], oy[16];
+            int np = 4;
+            px[0] = -pad_u;      py[0] = -pad_v;
+            px[1] = 1.0 + pad_u; py[1] = -pad_v;
+            px[2] = 1.0 + pad_u; py[2] = 1.0 + pad_v;
+            px[3] = -pad_u;      py[3] = 1.0 + pad_v;
+            for (int k = 0; k < 5 && np > 0; ++k) {
+                const double sgn = (k == 0 || side == 0) ? 1.0 : -1.0;       // dn keeps its sign on both sides
+                const double S = (double)p.K_slack * (double)M[k] * 1.01;
+                const double ca = sgn * FA[k] + S, cb = sgn * FB[k], cc = sgn * FC[k];   // keep ca + u cb + v cc >= 0
+                int m = 0;
+                double xp = px[np - 1], yp = py[np - 1], fp = ca + xp * cb + yp * cc;
+                for (int j = 0; j < np; ++j) {
+                    const double xc = px[j], yc = py[j], fc = ca + xc * cb + yc * cc;
+                    const bool in_c = fc >= 0.0, in_p = fp >= 0.0;
+                    if (in_c != in_p) {
+                        const double t = fp / (fp - fc);
+                        ox[m] = xp + t * (xc - xp); oy[m] = yp + t * (yc - yp); ++m;
+                    }
+                    if (in_c) { ox[m] = xc; oy[m] = yc; ++m; }
+                    xp = xc; yp = yc; fp = fc;
+                }
+                np = m;
+                for (int j = 0; j < np; ++j) { px[j] = ox[j]; py[j] = oy[j]; }
+            }
+            for (int j = 0; j < np; ++j) {
+                bu_lo = fmin(bu_lo, px[j]); bu_hi = fmax(bu_hi, px[j]);
+                bv_lo = fmin(bv_lo, py[j]); bv_hi = fmax(bv_hi, py[j]);
+            }
+        }
+    }
+    const bool empty = bu_lo > bu_hi;
+    cls[(size_t)4 * n_pad + i] = empty ? make_float4(1.0e30f, -1.0e30f, 1.0e30f, -1.0e30f)
+                                       : make_float4((float)bu_lo - 2.0e-6f, (float)bu_hi + 2.0e-6f,
+                                                     (float)bv_lo - 2.0e-6f, (float)bv_hi + 2.0e-6f);
 }
 
-hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const CameraPOD& cam,
+hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const RenderParams& p,
                               float4* d_cls, hipStream_t stream) {
     if (n_tris <= 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((n_tris + 255) / 256));
-    hipLaunchKernelGGL(cls_prepass_kernel, grid, block, 0, stream, d_rec, n_tris, n_pad, cam, d_cls);
+    hipLaunchKernelGGL(cls_prepass_kernel, grid, block, 0, stream, d_rec, n_tris, n_pad, p, d_cls);
     return hipGetLastError();
 }
 
@@ -1102,17 +1147,11 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     }
     TiledWork w = *work;
     if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
-    const int k1 = (variant == 2) ? 48 : kK1Max;
     int heavy = (variant == 2) ? 3 : kHeavyMin;          // tiles with more survivors are shared by all waves
     int blocks_per_cu = 2;
     if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::min(atoi(e), 128);   // tuning hooks (not part of the ABI)
     if (const char* e = getenv("CRT_SHADE_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(e));
-    hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    dim3 block(kTiledThreads);
-    dim3 grid_bin((unsigned)((p.nx + kRegionW - 1) / kRegionW), (unsigned)((p.row_count + kRegionH - 1) / kRegionH));
-    hipLaunchKernelGGL(bin_tiles_kernel, grid_bin, block, 0, stream, p, d_cls, n_pad, w, k1, heavy, d_stats);
-    e = hipGetLastError();
+    hipError_t e = launch_binning(p, d_cls, n_pad, w, heavy, d_stats, stream);
     if (e != hipSuccess) return e;
     if (ev_mid) {
         e = hipEventRecord(ev_mid, stream);   // splits the timing: [start, mid) = binning, [mid, stop) = shading
@@ -1153,6 +1192,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
 __global__ void __launch_bounds__(256)
 audit_tiles_kernel(RenderParams p, const float* __restrict__ rec, const uint32_t* __restrict__ state,
                    TiledWork w, unsigned long long* __restrict__ counters) {
+    __shared__ volatile uint32_t member[4][64], sure_of[4][64];   // per wavefront: 2048-bit windows of the tile's list
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tile_x = blockIdx.x * 2 + (wave & 1), tile_y = blockIdx.y * 2 + (wave >> 1);
@@ -1180,29 +1220,45 @@ audit_tiles_kernel(RenderParams p, const float* __restrict__ rec, const uint32_t
         if ((smp & 3) == 3) { ju = (smp & 4) ? 1.0f : 1.1641532e-10f; jv = (smp & 8) ? 1.0f : 1.1641532e-10f; }
         const float u = ((float)x + ju) / fnx, v = ((float)y + jv) / fny;
         const V3 d2 = unit_vector(unit_vector(camera_direction(p.cam, u, v)));
-        int cur = 0;
-        for (int i = 0; i < p.n_tris; ++i) {
-            const Rec16 rc = load_rec(rec, i);
-            const float dn = d2.x * rc.f[0] + d2.y * rc.f[1] + d2.z * rc.f[2];
-            const float hx = (d2.y * rc.f[5] - d2.z * rc.f[4]);
-            const float hy = (-(d2.x * rc.f[5] - d2.z * rc.f[3]));
-            const float hz = (d2.x * rc.f[4] - d2.y * rc.f[3]);
-            const float a = rc.f[6] * hx + rc.f[7] * hy + rc.f[8] * hz;
-            const float f = 1.0f / a;
-            const float uu = f * (rc.f[9] * hx + rc.f[10] * hy + rc.f[11] * hz);
-            const float vv = f * (d2.x * rc.f[12] + d2.y * rc.f[13] + d2.z * rc.f[14]);
-            const bool pass = !(dn < 0.0f) && !(a > -kTriEpsilon && a < kTriEpsilon) && !(uu < 0.0f || uu > 1.0f) &&
-                              !(vv < 0.0f || uu + vv > 1.0f);
-            while (cur < cnt && (int)(lst[cur] & 0x7fffffffu) < i) ++cur;
-            const bool in_list = cur < cnt && (int)(lst[cur] & 0x7fffffffu) == i;
-            const bool sure = in_list && (lst[cur] & kCullSureBit) != 0u;
-            const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass);
-            n_pass += (unsigned long long)__builtin_popcountll(mp);
-            if (mp != 0ull && !in_list) {
-                n_miss += (unsigned long long)__builtin_popcountll(mp);
-                if (lane == 0) atomicMax(&counters[3], ((unsigned long long)tile_id << 32) | (unsigned long long)i);
+        // lists are unordered: membership through a bitmap of 2048 triangle indices at a time
+        for (int c0 = 0; c0 < p.n_tris; c0 += 2048) {
+            member[wave][lane] = 0u;
+            sure_of[wave][lane] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < cnt; k += 64) {
+                const uint32_t e = lst[k];
+                const int rel = (int)(e & 0x7fffffffu) - c0;
+                if (rel >= 0 && rel < 2048) {
+                    atomicOr((unsigned*)&member[wave][rel >> 5], 1u << (rel & 31));
+                    if (e & kCullSureBit) atomicOr((unsigned*)&sure_of[wave][rel >> 5], 1u << (rel & 31));
+                }
             }
-            if (sure) n_cull += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(dn < 0.0f));
+            __builtin_amdgcn_wave_barrier();
+            const int c1 = min(c0 + 2048, p.n_tris);
+            for (int i = c0; i < c1; ++i) {
+                const Rec16 rc = load_rec(rec, i);
+                const float dn = d2.x * rc.f[0] + d2.y * rc.f[1] + d2.z * rc.f[2];
+                const float hx = (d2.y * rc.f[5] - d2.z * rc.f[4]);
+                const float hy = (-(d2.x * rc.f[5] - d2.z * rc.f[3]));
+                const float hz = (d2.x * rc.f[4] - d2.y * rc.f[3]);
+                const float a = rc.f[6] * hx + rc.f[7] * hy + rc.f[8] * hz;
+                const float f = 1.0f / a;
+                const float uu = f * (rc.f[9] * hx + rc.f[10] * hy + rc.f[11] * hz);
+                const float vv = f * (d2.x * rc.f[12] + d2.y * rc.f[13] + d2.z * rc.f[14]);
+                const bool pass = !(dn < 0.0f) && !(a > -kTriEpsilon && a < kTriEpsilon) && !(uu < 0.0f || uu > 1.0f) &&
+                                  !(vv < 0.0f || uu + vv > 1.0f);
+                const int rel = i - c0;
+                const bool in_list = ((member[wave][rel >> 5] >> (rel & 31)) & 1u) != 0u;
+                const bool sure = ((sure_of[wave][rel >> 5] >> (rel & 31)) & 1u) != 0u;
+                const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass);
+                n_pass += (unsigned long long)__builtin_popcountll(mp);
+                if (mp != 0ull && !in_list) {
+                    n_miss += (unsigned long long)__builtin_popcountll(mp);
+                    if (lane == 0) atomicMax(&counters[3], ((unsigned long long)tile_id << 32) | (unsigned long long)i);
+                }
+                if (sure) n_cull += (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(dn < 0.0f));
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (lane == 0) {
@@ -1216,12 +1272,7 @@ hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4*
                         const uint32_t* d_state, const TiledWork* work, unsigned long long* d_counters,
                         hipStream_t stream) {
     TiledWork w = *work;
-    hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    dim3 grid_bin((unsigned)((p.nx + kRegionW - 1) / kRegionW), (unsigned)((p.row_count + kRegionH - 1) / kRegionH));
-    hipLaunchKernelGGL(bin_tiles_kernel, grid_bin, dim3(kTiledThreads), 0, stream, p, d_cls, n_pad, w, kK1Max, kHeavyMin,
-                       (unsigned long long*)nullptr);
-    e = hipGetLastError();
+    hipError_t e = launch_binning(p, d_cls, n_pad, w, kHeavyMin, nullptr, stream);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)((w.tiles_x + 1) / 2), (unsigned)((w.tiles_y + 1) / 2));
     hipLaunchKernelGGL(audit_tiles_kernel, grid, dim3(256), 0, stream, p, d_rec, d_state, w, d_counters);

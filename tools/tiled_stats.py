@@ -24,10 +24,10 @@ torch.cuda.synchronize()
 out = (C.c_uint64 * 48)()
 L.crt_debug_tiled_stats(0, out)
 o = list(out)
-print("regions %d  sum1 %d (avg %.1f) max1 %d overflow1 %d" % (o[0], o[1], o[1] / max(o[0], 1), o[2], o[3]))
+print("bin wavefronts %d: regions entered %d (%.1f per wave), tiles box-tested %d (%.1f), tiles with survivors %d (%.1f)" % (o[0], o[1], o[1] / max(o[0], 1), o[2], o[2] / max(o[0], 1), o[3], o[3] / max(o[0], 1)))
 print("tiles %d  sum2 %d (avg %.1f) max2 %d overflow2 %d" % (o[4], o[5], o[5] / max(o[4], 1), o[6], o[7]))
 print("hist (bucket b: 2^(b-1) <= n < 2^b):", o[8:24])
 print("shade kernel cycles: heavy phase sum over blocks %d max %d | light phase sum over waves %d max %d | max wave total %d" % tuple(o[24:29]))
-print("bin kernel cycles: phase A sum over blocks %d max %d | phase A2 slowest wave %d" % tuple(o[29:32]))
+print("bin busiest wavefront: regions %d, tiles box-tested %d, cycles %d" % tuple(o[29:32]))
 print("heavy tiles %d (sum survivors %d): master wave cycles per tile: setup+merge+shade %.0f, own trace %.0f, wait B2 %.0f" % (o[35], o[36], o[32]/max(o[35],1), o[33]/max(o[35],1), o[34]/max(o[35],1)))
 print("kernel ms", api.last_kernel_times())
