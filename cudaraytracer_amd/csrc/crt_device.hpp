@@ -89,7 +89,7 @@ struct TiledWork {
     uint32_t pool_cap;               // entries
     uint2* tile_desc;                // per tile {pool offset, count | kNoList}
     uint32_t* queue;                 // kClasses weight classes x tiles_total tile ids
-    uint32_t* counters;              // kCtrQueueLen+c: queue length, kCtrCursor+c: consumer cursor
+    uint32_t* counters;              // kCtrWords words: queue lengths and consumer cursors (layout below)
     int tiles_x, tiles_y, tiles_total;
     uint32_t* tile_count;            // per tile: survivors (count pass), fill cursor (fill pass)
 };
@@ -97,10 +97,17 @@ struct TiledWork {
 // order for the persistent shading blocks): class c < kHeavyClasses holds tiles with more than
 // kClassMin[c] survivors (class 0 also: no list), the last class the light tiles.
 constexpr int kHeavyClasses = 9;
-constexpr int kClasses = kHeavyClasses + 1;
-constexpr int kCtrQueueLen = 2;      // counters[0..1] alias counters64[0]
-constexpr int kCtrCursor = 16;
-constexpr int kCtrWords = 32;
+constexpr int kLightClasses = 6;      // light tiles by survivors: >48, >32, >16, >8, >0, none
+constexpr int kClasses = kHeavyClasses + kLightClasses;
+constexpr int kCtrQueueLen = 2;      // counters[0..1] alias counters64[0]; [2 + c]: length of class c's queue
+// Consumer cursors of the shading kernel.  Returning atomics on one address serialise in L2
+// (~60 ns each, measured), so every hot cursor has its own 128-byte line and the light queue
+// is cut into kLightChunks chunks with one cursor each.
+constexpr int kCtrLine = 32;                       // words per 128-byte line
+constexpr int kCtrHeavyCursor = 2 * kCtrLine;      // next item of the concatenated heavy classes
+constexpr int kLightChunks = 64;
+constexpr int kCtrLightCursor = 3 * kCtrLine;      // + k * kCtrLine: next position inside chunk k
+constexpr int kCtrWords = (3 + kLightChunks) * kCtrLine;
 
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,

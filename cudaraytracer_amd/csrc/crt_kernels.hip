@@ -544,7 +544,7 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
 // the reference's float evaluation can commit (DESIGN.md §4.4 has the derivation).
 //   binning (lane = triangle) -> per-tile survivor lists; shading (lane = pixel) -> the reference
 //   arithmetic (exact_test) on the tile's survivors only.
-constexpr int kHeavyMin = 64;  // tiles with more survivors than this are traced by all 16 waves together (measured optimum, 16..128 swept)
+constexpr int kHeavyMin = 48;  // tiles with more survivors than this are traced by all waves of a block together (measured optimum, 12..64 swept)
 constexpr unsigned kNoList = 0xffffffffu;   // tile_desc.y: the pool was full, walk every triangle
 constexpr unsigned kCullSureBit = 0x80000000u;   // pool entry flag: the cull test cannot reject in this tile
 
@@ -755,12 +755,19 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
     }
 }
 
-// lane = tile: reserve the tile's pool space (one atomic per wavefront), descriptor, work queue.
-__global__ void __launch_bounds__(256)
-bin_alloc_kernel(TiledWork w, int heavy_min, unsigned long long* __restrict__ stats) {
-    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+// lane = tile: reserve the tile's pool space, descriptor, work queue.  Blocks of 1024 tiles
+// aggregate in LDS first: one global atomic per block for the pool and one per weight class.
+constexpr int kAllocThreads = 1024;
+__global__ void __launch_bounds__(kAllocThreads)
+bin_alloc_kernel(TiledWork w, int heavy_min, unsigned shade_blocks, unsigned long long* __restrict__ stats) {
+    __shared__ unsigned wave_total[kAllocThreads / 64], class_count[kClasses], class_base[kClasses];
+    __shared__ unsigned long long block_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x * kAllocThreads + tid;
     const bool valid = tile < w.tiles_total;
+    if (tid < kClasses) class_count[tid] = 0u;
+    // block b of the shading kernel starts with heavy item b; later items are pulled from here
+    if (blockIdx.x == 0 && tid == 0) w.counters[kCtrHeavyCursor] = shade_blocks;
     const unsigned cnt = valid ? w.tile_count[tile] : 0u;
     unsigned incl = cnt;                                   // inclusive scan inside the wavefront
 #pragma unroll
@@ -768,34 +775,54 @@ bin_alloc_kernel(TiledWork w, int heavy_min, unsigned long long* __restrict__ st
         const unsigned v = __shfl_up(incl, ofs, 64);
         if (lane >= ofs) incl += v;
     }
-    const unsigned total = __shfl(incl, 63, 64);
-    unsigned long long base = 0;
-    if (lane == 0 && total != 0u) base = atomicAdd(&w.counters64[0], (unsigned long long)total);
-    base = __shfl(base, 0, 64);
-    const bool fits = base + total <= (unsigned long long)w.pool_cap;   // per wavefront of tiles
-    if (!valid) return;
-    w.tile_desc[tile] = fits ? make_uint2((unsigned)base + (incl - cnt), cnt) : make_uint2(0u, kNoList);
-    if (!fits) w.tile_count[tile] = 0u;                    // no fill pass for this tile
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kAllocThreads / 64; ++k) {
+        const unsigned v = wave_total[k];
+        before += (k < wave) ? v : 0u;
+        total += v;
+    }
+    if (tid == 0) block_base = total ? atomicAdd(&w.counters64[0], (unsigned long long)total) : 0ull;
+    __syncthreads();
+    const unsigned long long base = block_base;
+    const bool fits = base + total <= (unsigned long long)w.pool_cap;   // per block of tiles
+    if (valid) {
+        w.tile_desc[tile] = fits ? make_uint2((unsigned)base + before + (incl - cnt), cnt) : make_uint2(0u, kNoList);
+        if (!fits) w.tile_count[tile] = 0u;                // no fill pass for this tile
+    }
     // weight class (heaviest first); the last heavy class starts at heavy_min, below is light
     const unsigned weight = fits ? cnt : 0xffffffffu;
     const unsigned mins[kHeavyClasses] = {1024u, 768u, 512u, 384u, 256u, 192u, 128u, 96u, (unsigned)heavy_min};
-    int c = kHeavyClasses;
+    const unsigned light_mins[kLightClasses - 1] = {48u, 32u, 16u, 8u, 0u};
+    int c = kClasses - 1;
+#pragma unroll
+    for (int k = kLightClasses - 2; k >= 0; --k)
+        if (weight > light_mins[k]) c = kHeavyClasses + k;
 #pragma unroll
     for (int k = kHeavyClasses - 1; k >= 0; --k)
         if (weight > mins[k] && weight > (unsigned)heavy_min) c = k;
-    // queue push, one atomic per wavefront and class present in it
+    if (!valid) c = -1;
+    // rank inside the block's share of the class queue: one LDS atomic per wavefront and class
     const unsigned long long lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(true);
+    unsigned rank = 0;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
     while (todo != 0ull) {
-        const int cc = __builtin_amdgcn_readlane(c, (int)__builtin_ctzll(todo));
+        const int leader = (int)__builtin_ctzll(todo);
+        const int cc = __builtin_amdgcn_readlane(c, leader);
         const unsigned long long mc = __builtin_amdgcn_ballot_w64(c == cc);
         unsigned qbase = 0;
-        if (lane == (int)__builtin_ctzll(mc)) qbase = atomicAdd(&w.counters[kCtrQueueLen + cc], (unsigned)__builtin_popcountll(mc));
-        qbase = (unsigned)__builtin_amdgcn_readlane((int)qbase, (int)__builtin_ctzll(mc));
-        if (c == cc) w.queue[(size_t)cc * w.tiles_total + qbase + (unsigned)__builtin_popcountll(mc & lanemask_lt)] = (uint32_t)tile;
+        if (lane == leader) qbase = atomicAdd(&class_count[cc], (unsigned)__builtin_popcountll(mc));
+        qbase = (unsigned)__builtin_amdgcn_readlane((int)qbase, leader);
+        if (c == cc) rank = qbase + (unsigned)__builtin_popcountll(mc & lanemask_lt);
         todo &= ~mc;
     }
-    if (stats) {                                            // diagnostics only (crt_debug_tiled_stats)
+    __syncthreads();
+    if (tid < kClasses && class_count[tid] != 0u) class_base[tid] = atomicAdd(&w.counters[kCtrQueueLen + tid], class_count[tid]);
+    __syncthreads();
+    if (valid) w.queue[(size_t)c * w.tiles_total + class_base[c] + rank] = (uint32_t)tile;
+    if (stats && valid) {                                   // diagnostics only (crt_debug_tiled_stats)
         atomicAdd(&stats[4], 1ull);
         atomicAdd(&stats[5], (unsigned long long)cnt);
         atomicMax(&stats[6], (unsigned long long)cnt);
@@ -806,9 +833,9 @@ bin_alloc_kernel(TiledWork w, int heavy_min, unsigned long long* __restrict__ st
     }
 }
 
-// binning of one launch: tables, count, allocate, fill (all on `stream`)
+// binning of one launch: count, allocate, fill (all on `stream`)
 static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int n_pad, const TiledWork& w,
-                                 int heavy_min, unsigned long long* d_stats, hipStream_t stream) {
+                                 int heavy_min, unsigned shade_blocks, unsigned long long* d_stats, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(w.tile_count, 0, (size_t)w.tiles_total * sizeof(uint32_t), stream);
@@ -819,8 +846,8 @@ static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int
     const int slices_x = std::max(1, std::min(region_nx, kBinWavesMin / std::max(n_waves * slices_y, 1)));
     const dim3 grid_tri((unsigned)n_waves, (unsigned)slices_y, (unsigned)slices_x);
     if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<0>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats);
-    hipLaunchKernelGGL(bin_alloc_kernel, dim3((unsigned)((w.tiles_total + 255) / 256)), dim3(256), 0, stream, w,
-                       heavy_min, d_stats);
+    hipLaunchKernelGGL(bin_alloc_kernel, dim3((unsigned)((w.tiles_total + kAllocThreads - 1) / kAllocThreads)), dim3(kAllocThreads), 0, stream, w,
+                       heavy_min, shade_blocks, d_stats);
     if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<1>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats);
     return hipGetLastError();
 }
@@ -858,15 +885,22 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
     const int n_tris = p.n_tris;
     const long long clk0 = stats ? (long long)clock64() : 0;
 
-    for (int c = 0; c < kHeavyClasses; ++c) {
-        const unsigned n_items = w.counters[kCtrQueueLen + c];
-        while (true) {
-            if (tid == 0) s_item = atomicAdd(&w.counters[kCtrCursor + c], 1u);
-            __syncthreads();
-            const unsigned item = s_item;
-            __syncthreads();
-            if (item >= n_items) break;
-            const int tile_id = (int)w.queue[(size_t)c * w.tiles_total + item];
+    // ---- heavy tiles: the classes form one list, heaviest first.  Block b starts with item b
+    // (no atomic: all blocks are resident), later items come from one shared cursor.
+    unsigned total_heavy = 0;
+#pragma unroll
+    for (int c = 0; c < kHeavyClasses; ++c) total_heavy += w.counters[kCtrQueueLen + c];
+    {
+        unsigned item = blockIdx.x;
+        while (item < total_heavy) {
+            int c = 0;
+            unsigned idx = item;
+            for (; c < kHeavyClasses - 1; ++c) {
+                const unsigned len = w.counters[kCtrQueueLen + c];
+                if (idx < len) break;
+                idx -= len;
+            }
+            const int tile_id = (int)w.queue[(size_t)c * w.tiles_total + idx];
             const uint2 desc = w.tile_desc[tile_id];
             const bool walk_all = desc.y == kNoList;
             const int n_src = walk_all ? n_tris : (int)desc.y;
@@ -951,18 +985,57 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                 }
             }
             __syncthreads();   // partial buffers are reused by the next tile
+            if (tid == 0) {
+                unsigned nxt = 0xffffffffu;
+                if (__hip_atomic_load(&w.counters[kCtrHeavyCursor], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total_heavy)
+                    nxt = atomicAdd(&w.counters[kCtrHeavyCursor], 1u);
+                s_item = nxt;
+            }
+            __syncthreads();
+            item = s_item;
+            __syncthreads();
         }
     }
     const long long clk1 = stats ? (long long)clock64() : 0;
 
     // ---- light tiles: one wave per tile, lane = pixel
-    const unsigned n_light = w.counters[kCtrQueueLen + kHeavyClasses];
+    // The light classes form one list, most survivors first; chunk k of kLightChunks owns the
+    // items k, k + 64, k + 128, ... and has its own cursor (own cache line).  A wave works
+    // through "its" chunk and then helps with whatever chunk still has tiles.
+    unsigned light_len[kLightClasses], n_light = 0;
+#pragma unroll
+    for (int c = 0; c < kLightClasses; ++c) {
+        light_len[c] = w.counters[kCtrQueueLen + kHeavyClasses + c];
+        n_light += light_len[c];
+    }
+    int chunk = (int)((blockIdx.x * WAVES + wave) % kLightChunks);
     while (true) {
-        unsigned item = 0;
-        if (lane == 0) item = atomicAdd(&w.counters[kCtrCursor + kHeavyClasses], 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_light) break;
-        const int tile_id = __builtin_amdgcn_readfirstlane((int)w.queue[(size_t)kHeavyClasses * w.tiles_total + item]);
+        const unsigned c_len = (n_light + (unsigned)(kLightChunks - 1 - chunk)) / kLightChunks;   // items g = pos * 64 + chunk < n_light
+        unsigned pos = 0xffffffffu;
+        if (c_len != 0u) {
+            if (lane == 0) pos = atomicAdd(&w.counters[kCtrLightCursor + chunk * kCtrLine], 1u);
+            pos = __builtin_amdgcn_readfirstlane(pos);
+        }
+        if (pos >= c_len) {   // chunk exhausted (or empty): look at all cursors at once
+            unsigned left = 0;
+            if (lane < kLightChunks) {
+                const unsigned len_l = (n_light + (unsigned)(kLightChunks - 1 - lane)) / kLightChunks;
+                const unsigned cur = __hip_atomic_load(&w.counters[kCtrLightCursor + lane * kCtrLine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                left = (cur < len_l) ? 1u : 0u;
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(left != 0u);
+            if (m == 0ull) break;
+            const int r = chunk + 1;                                   // first candidate: the next chunk
+            const unsigned long long rot = (r >= 64) ? m : ((m >> r) | (m << (64 - r)));
+            chunk = (r + (int)__builtin_ctzll(rot)) & (kLightChunks - 1);
+            continue;
+        }
+        unsigned item = pos * kLightChunks + (unsigned)chunk;
+        int lc = 0;
+#pragma unroll
+        for (int c = 0; c < kLightClasses - 1; ++c)
+            if (lc == c && item >= light_len[c]) { item -= light_len[c]; lc = c + 1; }
+        const int tile_id = __builtin_amdgcn_readfirstlane((int)w.queue[(size_t)(kHeavyClasses + lc) * w.tiles_total + item]);
         const uint2 desc = w.tile_desc[tile_id];
         const int cnt = __builtin_amdgcn_readfirstlane((int)desc.y);
         const uint32_t* __restrict__ lst = w.pool + __builtin_amdgcn_readfirstlane(desc.x);
@@ -1148,16 +1221,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     TiledWork w = *work;
     if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
     int heavy = (variant == 2) ? 3 : kHeavyMin;          // tiles with more survivors are shared by all waves
-    int blocks_per_cu = 2;
     if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::min(atoi(e), 128);   // tuning hooks (not part of the ABI)
-    if (const char* e = getenv("CRT_SHADE_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(e));
-    hipError_t e = launch_binning(p, d_cls, n_pad, w, heavy, d_stats, stream);
-    if (e != hipSuccess) return e;
-    if (ev_mid) {
-        e = hipEventRecord(ev_mid, stream);   // splits the timing: [start, mid) = binning, [mid, stop) = shading
-        if (e != hipSuccess) return e;
-    }
-    dim3 grid_shade((unsigned)std::max(1, std::min(n_cus * blocks_per_cu, w.tiles_total)));
     // Waves that share a heavy tile: 8 when the launch has plenty of tiles per CU (throughput),
     // 16 when it is small (a rank of a multi-GPU split): then the longest tile bounds the time.
     int dbg_repeat = 1, group = (w.tiles_total >= n_cus * 96) ? 8 : 16;
@@ -1167,20 +1231,33 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* e = getenv("CRT_DEBUG_WALK_REPEAT")) dbg_repeat = atoi(e);   // timing experiments only
     bool vrec = variant != 3;   // light tiles: records staged in LDS (VGPR operands); variant 3 keeps the scalar-operand walk (A/B)
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
-    int g8n = n_cus * blocks_per_cu * 2;
-    if (const char* e = getenv("CRT_SHADE_GRID")) g8n = std::max(1, atoi(e));
-    const dim3 g8((unsigned)std::max(1, std::min(g8n, w.tiles_total)));
-#define CRT_LAUNCH_SHADE(V, O, W_, GRID)                                                                              \
-    hipLaunchKernelGGL((shade_tiles_kernel<V, O, W_>), GRID, dim3(W_ * 64), 0, stream, p, d_rec, d_shade_n, d_state, \
-                       d_rgb, w, d_stats, dbg_repeat)
+    using ShadeFn = void (*)(RenderParams, const float*, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int);
+    ShadeFn fn;
     if (group == 8) {
-        if (vrec) { if (occ == 6) CRT_LAUNCH_SHADE(true, 6, 8, g8); else if (occ == 4) CRT_LAUNCH_SHADE(true, 4, 8, g8); else CRT_LAUNCH_SHADE(true, 8, 8, g8); }
-        else      { if (occ == 6) CRT_LAUNCH_SHADE(false, 6, 8, g8); else if (occ == 4) CRT_LAUNCH_SHADE(false, 4, 8, g8); else CRT_LAUNCH_SHADE(false, 8, 8, g8); }
+        occ = (occ == 6 || occ == 4) ? occ : 8;
+        fn = vrec ? (occ == 6 ? shade_tiles_kernel<true, 6, 8> : occ == 4 ? shade_tiles_kernel<true, 4, 8> : shade_tiles_kernel<true, 8, 8>)
+                  : (occ == 6 ? shade_tiles_kernel<false, 6, 8> : occ == 4 ? shade_tiles_kernel<false, 4, 8> : shade_tiles_kernel<false, 8, 8>);
     } else {
-        if (vrec) { if (occ == 4) CRT_LAUNCH_SHADE(true, 4, 16, grid_shade); else CRT_LAUNCH_SHADE(true, 8, 16, grid_shade); }
-        else      { if (occ == 4) CRT_LAUNCH_SHADE(false, 4, 16, grid_shade); else CRT_LAUNCH_SHADE(false, 8, 16, grid_shade); }
+        group = 16;
+        occ = (occ == 4) ? 4 : 8;
+        fn = vrec ? (occ == 4 ? shade_tiles_kernel<true, 4, 16> : shade_tiles_kernel<true, 8, 16>)
+                  : (occ == 4 ? shade_tiles_kernel<false, 4, 16> : shade_tiles_kernel<false, 8, 16>);
     }
-#undef CRT_LAUNCH_SHADE
+    // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b)
+    int resident = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, fn, group * 64, 0);
+    if (e != hipSuccess) return e;
+    int n_blocks = n_cus * std::max(resident, 1);
+    if (const char* ev = getenv("CRT_SHADE_GRID")) n_blocks = std::max(1, atoi(ev));
+    n_blocks = std::max(1, std::min(n_blocks, w.tiles_total));
+    e = launch_binning(p, d_cls, n_pad, w, heavy, (unsigned)n_blocks, d_stats, stream);
+    if (e != hipSuccess) return e;
+    if (ev_mid) {
+        e = hipEventRecord(ev_mid, stream);   // splits the timing: [start, mid) = binning, [mid, stop) = shading
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)n_blocks), dim3((unsigned)group * 64), 0, stream, p, d_rec, d_shade_n, d_state,
+                       d_rgb, w, d_stats, dbg_repeat);
     return hipGetLastError();
 }
 
@@ -1272,7 +1349,7 @@ hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4*
                         const uint32_t* d_state, const TiledWork* work, unsigned long long* d_counters,
                         hipStream_t stream) {
     TiledWork w = *work;
-    hipError_t e = launch_binning(p, d_cls, n_pad, w, kHeavyMin, nullptr, stream);
+    hipError_t e = launch_binning(p, d_cls, n_pad, w, kHeavyMin, 0u, nullptr, stream);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)((w.tiles_x + 1) / 2), (unsigned)((w.tiles_y + 1) / 2));
     hipLaunchKernelGGL(audit_tiles_kernel, grid, dim3(256), 0, stream, p, d_rec, d_state, w, d_counters);
