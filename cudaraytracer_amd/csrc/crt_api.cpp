@@ -626,8 +626,8 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     p.strip_rows = strip_rows; p.strip_step = strip_step;
     p.n_tris = scene->n_tris;
     p.rng_count = count;
-    p.inv_nx = 1.0 / (double)(float)nx;
-    p.inv_ny = 1.0 / (double)(float)ny;
+    p.rnx = 1.0f / (float)nx;
+    p.rny = 1.0f / (float)ny;
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
 
     if (kernel_variant != 0) {
@@ -667,8 +667,8 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     p.strip_rows = 32; p.strip_step = 1;
     p.n_tris = scene->n_tris;
     p.rng_count = (long long)nx * ny;
-    p.inv_nx = 1.0 / (double)(float)nx;
-    p.inv_ny = 1.0 / (double)(float)ny;
+    p.rnx = 1.0f / (float)nx;
+    p.rny = 1.0f / (float)ny;
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
     unsigned long long* d = nullptr;
     int rc = ensure_workspace(nx, ny);
@@ -725,8 +725,16 @@ int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t* mismatc
     unsigned long long* d = nullptr;
     HIP_TRY(hipMalloc(&d, sizeof(unsigned long long)));
     hipError_t e = hipMemset(d, 0, sizeof(unsigned long long));
-    if (e == hipSuccess) e = crt::launch_check_reciprocal(mode, (uint32_t)exp_lo, (uint32_t)exp_hi, d, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (mode == 1) {   // significand chunks: one launch (about half a second) per chunk
+        if (exp_hi > 63) { (void)hipFree(d); return fail(CRT_ERR_INVALID, "crt_debug_check_division: mode 1 takes chunks 0..63"); }
+        for (int c = exp_lo; c <= exp_hi && e == hipSuccess; ++c) {
+            e = crt::launch_check_reciprocal(1, (uint32_t)c, (uint32_t)c, d, nullptr);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+    } else {
+        if (e == hipSuccess) e = crt::launch_check_reciprocal(mode, (uint32_t)exp_lo, (uint32_t)exp_hi, d, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
     unsigned long long h = 0;
     if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
     (void)hipFree(d);

@@ -54,7 +54,7 @@ struct RenderParams {
     int strip_rows, strip_step;
     int n_tris;
     long long rng_count;         // number of states = row_count * nx (SoA stride); element = ly * nx + x
-    double inv_nx, inv_ny;       // 1.0 / double(float(nx)), 1.0 / double(float(ny)) (host, correctly rounded)
+    float rnx, rny;              // 1.0f / float(nx), 1.0f / float(ny) (host, IEEE)
     float pos_du, pos_dv;        // tiled variant: position slack of the camera in (u,v) (host, camera_slacks)
     float K_slack;               // tiled variant: slack factor of the form values, whole screen (host, camera_slacks)
 };

@@ -169,28 +169,34 @@ struct V3 {
     float x, y, z;
 };
 
-// ---- correctly rounded fp32 quotients through fp64 (used only in the tiled shading kernel).
-// For floats x, y the quotient x/y is either a float or at least 2^-49 (relative) away from
-// every midpoint of two adjacent floats: x - m*y is a non-zero multiple of
-// ulp(m)*ulp(y)/2 for a midpoint m, and m*y cannot be a float unless y is a power of two
-// (then x/y is exact).  Hence RN24(x * r) == RN24(x / y) for ANY double r with
-// |r - 1/y| <= 2^-50/|y| : one fp64 reciprocal serves the three components of unit_vector,
-// and a host-computed 1.0/double(nx) serves `(x + U) / float(nx)` (core/render.h:116-117).
-// rcp64_of_float: v_rcp_f64 + two Newton steps; its accuracy (<= 2 ulp of fp64 = 2^-51) is
-// checked for EVERY positive normal float by crt_debug_check_reciprocal (mode 1).
-__device__ __forceinline__ double rcp64_of_float(float y) {
-    const double yd = (double)y;
-    double r = __builtin_amdgcn_rcp(yd);
-    double e = __builtin_fma(-yd, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-yd, r, 1.0);
-    return __builtin_fma(r, e, r);
+// ---- correctly rounded fp32 quotients without the IEEE division sequence (used only in the
+// tiled shading kernel).  With y = RN(1/b):
+//     q0 = RN(x*y);   r = RN(x - q0*b)  (fma: exact);   q = RN(q0 + r*y)  ==  RN(x / b)
+// for every pair of floats whose quotient, remainder and reciprocal stay in the normal range.
+// Proof by exhaustion: tools/div_exhaustive.hip compares q with the IEEE quotient for all
+// 2^23 x 2^23 pairs of significands (7.04e13 pairs, 0 mismatches: profiles/r1_div_exhaustive.txt);
+// a power-of-two scaling of x or b changes no rounding while nothing under/overflows, which
+// the callers' range guards ensure.  y itself is reciprocal<true> (v_rcp_f32 + one Newton
+// step), equal to the IEEE 1.0f/b for every float in 2^-100..2^100 (GPU test, exhaustive).
+template <bool FAST>
+__device__ __forceinline__ float reciprocal(float a) {
+    if (FAST) {
+        float r = __builtin_amdgcn_rcpf(a);
+        float e = __builtin_fmaf(-a, r, 1.0f);
+        return __builtin_fmaf(e, r, r);
+    }
+    return 1.0f / a;
 }
 
-__device__ __forceinline__ float mul_round(float x, double r) { return (float)((double)x * r); }
+__device__ __forceinline__ float div_by_rcp(float x, float b, float y) {
+    const float q0 = x * y;
+    const float r = __builtin_fmaf(-q0, b, x);
+    return __builtin_fmaf(r, y, q0);
+}
 
-// unit_vector through the fp64 reciprocal; identical bits to unit_vector below whenever the
-// length is an ordinary float (2^-100 < len < 2^100), else the IEEE divides.
+// unit_vector through div_by_rcp; identical bits to unit_vector below.  Guard: every component
+// >= 2^-80 in magnitude (so an exact zero component takes the IEEE path too) and len <= 2^40:
+// then |q| >= 2^-120, the exact remainder is a multiple of 2^-126 and 1/len is in 2^-40..2^80.
 __device__ __forceinline__ V3 unit_vector_fast(V3 v);
 
 // unit_vector(v) = v / v.length()  (core/vec3.h:191-193,38-40,105-107): three IEEE divides.
@@ -211,10 +217,19 @@ __device__ __forceinline__ V3 camera_direction(const CameraPOD& c, float u, floa
 
 __device__ __forceinline__ V3 unit_vector_fast(V3 v) {
     float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-    const bool ordinary = len > 7.8886090522101181e-31f && len < 1.2676506002282294e30f;   // 2^-100 .. 2^100
+    const float amin = fminf(fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
+    const bool ordinary = amin >= 8.2718061255302767e-25f && len <= 1099511627776.0f;   // 2^-80, 2^40 (NaN -> false)
     if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return V3{v.x / len, v.y / len, v.z / len};
-    const double r = rcp64_of_float(len);
-    return V3{mul_round(v.x, r), mul_round(v.y, r), mul_round(v.z, r)};
+    const float y = reciprocal<true>(len);
+    return V3{div_by_rcp(v.x, len, y), div_by_rcp(v.y, len, y), div_by_rcp(v.z, len, y)};
+}
+
+// the y component of unit_vector(v) alone (sky-only tiles)
+__device__ __forceinline__ float unit_vector_fast_y(V3 v) {
+    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const bool ordinary = fabsf(v.y) >= 8.2718061255302767e-25f && len <= 1099511627776.0f;
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return v.y / len;
+    return div_by_rcp(v.y, len, reciprocal<true>(len));
 }
 
 // backgroundSky (core/render.h:41-46) given v = unit_vector(d0) already.
@@ -255,15 +270,6 @@ __device__ __forceinline__ Rec16 load_rec(const float* __restrict__ rec, int idx
 // is_exact).  On this path |a| >= EPSILON = 2^-20 for every lane whose result is used and
 // |a| <= |e1||e2| <= 2^84 because the host only selects FAST for scenes whose coordinates are
 // bounded by 2^38; otherwise the compiler's IEEE sequence is used.
-template <bool FAST>
-__device__ __forceinline__ float reciprocal(float a) {
-    if (FAST) {
-        float r = __builtin_amdgcn_rcpf(a);
-        float e = __builtin_fmaf(-a, r, 1.0f);
-        return __builtin_fmaf(e, r, r);
-    }
-    return 1.0f / a;
-}
 
 // Votes are kept as 64-bit lane masks in SGPRs (v_cmp -> s_and_b64 -> s_cbranch_scc), the
 // per-lane predicate is only rebuilt for the final conditional update.
@@ -411,7 +417,7 @@ __device__ __forceinline__ void exact_test_vec(const RecV& rc, int i_raw, V3 d, 
 // (hitable/hitable_list.h:76-91): minimum t over all triangles that pass
 // Triangle::collision_detection (any sign of t, no range test), lowest index on ties, NaN
 // never accepted.
-template <bool FASTDIV = false, class Traverse>
+template <bool FASTDIV = false, bool SKYONLY = false, class Traverse>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly,
                                              const float* __restrict__ shade_n,
                                              uint32_t* __restrict__ state, float* __restrict__ rgb,
@@ -435,9 +441,9 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 
     for (int smp = 0; smp < p.samples; ++smp) {
         float u, v;
-        if (FASTDIV) {   // same bits as the IEEE divides (see rcp64_of_float)
-            u = mul_round((float)x + xw_uniform(rs), p.inv_nx);        // render.h:116
-            v = mul_round((float)y + xw_uniform(rs), p.inv_ny);        // render.h:117
+        if (FASTDIV) {   // same bits as the IEEE divides (see div_by_rcp; numerators >= 2^-33, divisors 1..2^24)
+            u = div_by_rcp((float)x + xw_uniform(rs), fnx, p.rnx);     // render.h:116
+            v = div_by_rcp((float)y + xw_uniform(rs), fny, p.rny);     // render.h:117
         } else {
             u = ((float)x + xw_uniform(rs)) / fnx;                     // render.h:116
             v = ((float)y + xw_uniform(rs)) / fny;                     // render.h:117
@@ -455,6 +461,13 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
         // direction = lower_left_corner + s*horizontal + t*vertical - origin - offset, offset = 0
         V3 d0 = camera_direction(c, u, v);
 
+        if (SKYONLY) {   // a tile without survivors: every sample is background, which needs unit_vector(d0).y only
+            const V3 sky = sky_from_unit(V3{0.0f, unit_vector_fast_y(d0), 0.0f});
+            colx += sky.x;                                             // render.h:85
+            coly += sky.y;
+            colz += sky.z;
+            continue;
+        }
         // world list Transform then triangle Transform: ScaleRay normalises twice
         // (transform.h:50-54 via hitable.h:34 at both levels).
         V3 d1 = FASTDIV ? unit_vector_fast(d0) : unit_vector(d0);
@@ -1056,7 +1069,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (x < p.nx && ly < p.row_count) {
+        if (cnt == 0) {   // background only (most tiles of a typical frame)
+            if (x < p.nx && ly < p.row_count)
+                render_pixel<true, true>(p, x, ly, shade_n, state, rgb, true, [](V3, float&, int&) {});
+        } else if (x < p.nx && ly < p.row_count) {
             render_pixel<true>(p, x, ly, shade_n, state, rgb, true,
                          [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
@@ -1371,29 +1387,41 @@ check_reciprocal_kernel(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* __
     if (mine) atomicAdd(bad, mine);
 }
 
-// mode 1: |rcp64_of_float(y) - 1/y| <= 2 ulp(fp64) for every float of the exponent range;
-// mode 2: mul_round(x, rcp64_of_float(y)) == x / y for 64 pseudo-random numerators x per y.
+// Self-checks of div_by_rcp (crt_debug_check_division).
+// mode 1: exhaustive over significands — divisors b = 1.mb for mb in chunks [lo, hi] of 64
+//         (2^17 divisors per chunk), numerators x = 1.mx for ALL 2^23 mx: 1.1e12 pairs per chunk,
+//         7.04e13 for chunks 0..63.  Quotients cover both result binades.
+// mode 2: every float divisor of the biased-exponent range [lo, hi], 64 pseudo-random numerators
+//         each with exponents 0..60 below the divisor's and random signs (scaling / sign paths).
 __global__ void __launch_bounds__(256)
-check_division_kernel(int mode, uint32_t exp_lo, uint32_t exp_hi, unsigned long long* __restrict__ bad) {
-    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long total = (unsigned long long)(exp_hi - exp_lo + 1) << 24;
+check_division_kernel(int mode, uint32_t lo, uint32_t hi, unsigned long long* __restrict__ bad) {
     unsigned long long mine = 0;
-    for (; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t bits = ((uint32_t)(i & 1) << 31) | ((exp_lo + (uint32_t)(i >> 24)) << 23) | (uint32_t)((i >> 1) & 0x7fffff);
-        const float y = __uint_as_float(bits);
-        const double r = rcp64_of_float(y), ref = 1.0 / (double)y;
-        if (mode == 1) {
-            const long long d = (long long)__double_as_longlong(r) - (long long)__double_as_longlong(ref);
-            mine += (d > 2 || d < -2) ? 1ull : 0ull;
-        } else {
+    if (mode == 1) {
+        const unsigned long long n_div = (unsigned long long)(hi - lo + 1) << 17;
+        for (unsigned long long d = blockIdx.x; d < n_div; d += gridDim.x) {
+            const uint32_t mb = (lo << 17) + (uint32_t)d;
+            const float b = __uint_as_float(0x3f800000u | mb);
+            const float y = reciprocal<true>(b);
+            for (uint32_t mx = threadIdx.x; mx < (1u << 23); mx += blockDim.x) {
+                const float x = __uint_as_float(0x3f800000u | mx);
+                mine += (__float_as_uint(div_by_rcp(x, b, y)) != __float_as_uint(x / b)) ? 1ull : 0ull;
+            }
+        }
+    } else {
+        unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned long long total = (unsigned long long)(hi - lo + 1) << 24;
+        for (; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+            const uint32_t eb = lo + (uint32_t)(i >> 24);
+            const uint32_t bits = ((uint32_t)(i & 1) << 31) | (eb << 23) | (uint32_t)((i >> 1) & 0x7fffff);
+            const float b = __uint_as_float(bits);
+            const float y = reciprocal<true>(b);
             uint32_t h = bits * 2654435761u + 12345u;
             for (int k = 0; k < 64; ++k) {
                 h = h * 1664525u + 1013904223u;
-                // numerator: random mantissa, exponent within +-40 of y's (quotients from 2^-40 to 2^40), random sign
-                const uint32_t ex = (uint32_t)((int)(exp_lo + (uint32_t)(i >> 24)) + (int)((h >> 9) % 81u) - 40);
-                const float x = __uint_as_float(((h & 1u) << 31) | ((ex & 0xffu) << 23) | ((h >> 8) & 0x7fffffu));
-                if (ex == 0u || ex >= 255u) continue;
-                mine += (__float_as_uint(mul_round(x, r)) != __float_as_uint(x / y)) ? 1ull : 0ull;
+                const int ex = (int)eb - (int)((h >> 9) % 61u);
+                if (ex <= 0) continue;
+                const float x = __uint_as_float(((h & 1u) << 31) | ((uint32_t)ex << 23) | ((h >> 8) & 0x7fffffu));
+                mine += (__float_as_uint(div_by_rcp(x, b, y)) != __float_as_uint(x / b)) ? 1ull : 0ull;
             }
         }
     }
@@ -1405,7 +1433,7 @@ hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, u
     if (mode == 0)
         hipLaunchKernelGGL(check_reciprocal_kernel, dim3(4096), dim3(256), 0, stream, exp_lo, exp_hi, d_bad);
     else
-        hipLaunchKernelGGL(check_division_kernel, dim3(4096), dim3(256), 0, stream, mode, exp_lo, exp_hi, d_bad);
+        hipLaunchKernelGGL(check_division_kernel, dim3(mode == 1 ? 32768 : 4096), dim3(256), 0, stream, mode, exp_lo, exp_hi, d_bad);
     return hipGetLastError();
 }
 

@@ -194,11 +194,13 @@ int crt_debug_audit_tiles(const crt_scene *scene, const crt_camera *camera, int 
  * exponent lies in [exp_lo, exp_hi], both signs, on the current device; *mismatches must be 0
  * for [27, 227] (2^-100 .. 2^100). */
 int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t *mismatches);
-/* Same idea for the fp64-reciprocal quotients of the shading kernel (`x / len` in unit_vector,
- * `(x + U) / float(nx)`).  mode 0 = the check above; mode 1 = the fp64 reciprocal of every float y
- * of the exponent range is within 2 ulp(fp64) of 1/y — which makes float(double(x)*r) the
- * correctly rounded x/y for every float x (proof in csrc/crt_kernels.hip); mode 2 = direct
- * comparison with the IEEE quotient for 64 pseudo-random numerators per y. */
+/* Same idea for the quotients of the shading kernel (`x / len` in unit_vector,
+ * `(x + U) / float(nx)`), computed as q0 = x*y, r = fma(-q0, b, x), q = fma(r, y, q0) with
+ * y = the reciprocal above.  mode 0 = the check above; mode 1 = exhaustive over significands:
+ * divisors 1.mb for mb in chunks [exp_lo, exp_hi] of 64 (2^17 divisors each) against ALL 2^23
+ * numerator significands (chunks 0..63 = 7.04e13 pairs = every pair of significands);
+ * mode 2 = every float divisor with biased exponent in [exp_lo, exp_hi], 64 pseudo-random
+ * numerators each, exponents up to 60 below the divisor's, both signs. */
 int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t *mismatches);
 
 /* Duration in milliseconds of the last crt_render_rows main kernel launched through this
