@@ -32,6 +32,8 @@ NX, NY, SPP = 1920, 1080, 64
 N_LAT, N_LON = 200, 250                     # 100 000 triangles
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 REC_BYTES = 64                              # derived triangle record (csrc/crt_device.hpp)
+CLS_BYTES = 80                              # classification record: 5 float4 planes
+BASE_BYTES = 48                             # per-triangle input of tri_prepass: 12 floats (csrc/crt_device.hpp kBaseFloats)
 
 
 def build_scene_obj(tmpdir):
@@ -51,13 +53,16 @@ def algorithmic_bytes_brute(nx, rows, spp, n_tris):
     return tiles * spp * n_tris * REC_BYTES + px * 12 + px * 48
 
 
-def algorithmic_bytes_tiled(nx, rows, spp, n_tris, regions, sum1, sum2):
-    """Tiled variant.  bin kernel: every 128x32 region streams all 64-B
-    classification records once, every tile re-reads its region's survivors twice (count +
-    write pass) and writes its list; shade kernel: every (tile, sample) reads the 64-B exact
-    record of each of the tile's survivors, the list once per tile, plus framebuffer + RNG."""
+def algorithmic_bytes_tiled(nx, rows, spp, n_tris, base_bytes, sum2):
+    """Tiled variant.  binning (five small kernels, lane = triangle): tri_prepass
+    reads the base record and writes the 64-B exact record, cls_prepass reads it and writes the
+    80-B classification record, the count and the fill pass of bin_tri_kernel read that once
+    each; every list entry is written once (4 B), every tile has a count and a descriptor (12 B).
+    shade kernel: every (tile, sample) reads the 64-B exact record of each of the tile's
+    survivors, the list once per tile, plus framebuffer + RNG state."""
     px = nx * rows
-    bin_b = regions * n_tris * REC_BYTES + 2 * 64 * sum1 * REC_BYTES + sum2 * 4
+    tiles = ((nx + 7) // 8) * ((rows + 7) // 8)
+    bin_b = n_tris * (base_bytes + REC_BYTES + REC_BYTES + CLS_BYTES + 2 * CLS_BYTES) + sum2 * 4 + tiles * 12
     shade_b = spp * sum2 * REC_BYTES + sum2 * 4 + px * 12 + px * 48
     return bin_b, shade_b
 
@@ -180,19 +185,20 @@ def main():
         value = rays / elapsed / 1e6
         k_tot, k_bin, k_shade = [float(x) for x in np.mean(np.array(kernel_ms), axis=0)]
         if tiled:
-            bin_b, shade_b = algorithmic_bytes_tiled(NX, br.row_count, args.spp, n_tris, st[0], st[1], st[5])
+            bin_b, shade_b = algorithmic_bytes_tiled(NX, br.row_count, args.spp, n_tris, BASE_BYTES, st[5])
             kernels = {
-                "bin_tiles_kernel": {"ms": k_bin, "algorithmic_bytes": bin_b, "GB/s": bin_b / (k_bin * 1e-3) / 1e9,
-                                     "note": "lane = triangle, coalesced stream of 64-B classification records, "
-                                             "once per 128x32 region (L2/MALL resident: %.1f MB)" % (n_tris * 64 / 1e6)},
+                "binning": {"ms": k_bin, "algorithmic_bytes": bin_b, "GB/s": bin_b / (k_bin * 1e-3) / 1e9,
+                            "note": "tri_prepass + cls_prepass + bin_tri_kernel<count> + bin_alloc_kernel + "
+                                    "bin_tri_kernel<fill>: lane = triangle, one coalesced pass each over the "
+                                    "per-triangle records; launch-latency bound at this size"},
                 "shade_tiles_kernel": {"ms": k_shade, "algorithmic_bytes": shade_b,
                                        "GB/s": shade_b / (k_shade * 1e-3) / 1e9,
                                        "note": "lane = pixel, exact reference arithmetic on tile survivors; "
-                                               "VALU-issue bound (DESIGN.md §5)"},
+                                               "VALU bound (DESIGN.md §5)"},
             }
-            dom = "shade_tiles_kernel" if k_shade >= k_bin else "bin_tiles_kernel"
+            dom = "shade_tiles_kernel" if k_shade >= k_bin else "binning"
             alg, k_ms = kernels[dom]["algorithmic_bytes"], kernels[dom]["ms"]
-            survivors = {"regions": st[0], "region_survivors_sum": st[1], "tiles": st[4],
+            survivors = {"bin_wavefronts": st[0], "regions_entered": st[1], "tiles": st[4],
                          "tile_survivors_sum": st[5], "tile_survivors_max": st[6], "pool_overflows": st[7]}
         else:
             alg, k_ms, dom = algorithmic_bytes_brute(NX, br.row_count, args.spp, n_tris), k_tot, "render_list_kernel"

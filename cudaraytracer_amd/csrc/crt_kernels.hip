@@ -194,9 +194,7 @@ __device__ __forceinline__ float div_by_rcp(float x, float b, float y) {
     return __builtin_fmaf(r, y, q0);
 }
 
-// unit_vector through div_by_rcp; identical bits to unit_vector below.  Guard: every component
-// >= 2^-80 in magnitude (so an exact zero component takes the IEEE path too) and len <= 2^40:
-// then |q| >= 2^-120, the exact remainder is a multiple of 2^-126 and 1/len is in 2^-40..2^80.
+// unit_vector through sqrt_normal and div_by_rcp; identical bits to unit_vector below.
 __device__ __forceinline__ V3 unit_vector_fast(V3 v);
 
 // unit_vector(v) = v / v.length()  (core/vec3.h:191-193,38-40,105-107): three IEEE divides.
@@ -215,20 +213,44 @@ __device__ __forceinline__ V3 camera_direction(const CameraPOD& c, float u, floa
     return d;
 }
 
+// Correctly rounded sqrt of a NORMAL float (2^-100 <= x <= 2^100): v_sqrt_f32 is within one ulp,
+// the exact residuals of its two neighbours decide — the compiler's own sqrtf expansion without
+// the denormal pre-scaling and the class fix-up.  Equal to sqrtf for every float of that range
+// (crt_debug_check_division mode 3, exhaustive).
+__device__ __forceinline__ float sqrt_normal(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __int_as_float(__float_as_int(s) - 1), hi = __int_as_float(__float_as_int(s) + 1);
+    const float r_lo = __builtin_fmaf(-lo, s, x), r_hi = __builtin_fmaf(-hi, s, x);
+    s = (r_lo <= 0.0f) ? lo : s;
+    s = (r_hi > 0.0f) ? hi : s;
+    return s;
+}
+
+// Guard of the fast path: every component >= 2^-40 in magnitude (so an exact zero component
+// takes the IEEE path too) and len <= 2^40.  Then the sum of squares is a normal float >= 2^-80,
+// |q| >= 2^-80, the exact remainder is a multiple of 2^-126 and 1/len is in 2^-40..2^40.
+// Anything else — including inf/NaN, for which both tests are false — recomputes with the
+// IEEE sqrtf and divisions.
 __device__ __forceinline__ V3 unit_vector_fast(V3 v) {
-    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    float len = sqrt_normal(s2);
     const float amin = fminf(fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
-    const bool ordinary = amin >= 8.2718061255302767e-25f && len <= 1099511627776.0f;   // 2^-80, 2^40 (NaN -> false)
-    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return V3{v.x / len, v.y / len, v.z / len};
+    const bool ordinary = amin >= 9.094947017729282e-13f && len <= 1099511627776.0f;   // 2^-40, 2^40
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) {
+        len = sqrtf(s2);
+        return V3{v.x / len, v.y / len, v.z / len};
+    }
     const float y = reciprocal<true>(len);
     return V3{div_by_rcp(v.x, len, y), div_by_rcp(v.y, len, y), div_by_rcp(v.z, len, y)};
 }
 
 // the y component of unit_vector(v) alone (sky-only tiles)
 __device__ __forceinline__ float unit_vector_fast_y(V3 v) {
-    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-    const bool ordinary = fabsf(v.y) >= 8.2718061255302767e-25f && len <= 1099511627776.0f;
-    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return v.y / len;
+    const float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    float len = sqrt_normal(s2);
+    // s2 >= v.y^2 >= 2^-80 up to rounding: normal; x, z only add to it
+    const bool ordinary = fabsf(v.y) >= 9.094947017729282e-13f && len <= 1099511627776.0f;
+    if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return v.y / sqrtf(s2);
     return div_by_rcp(v.y, len, reciprocal<true>(len));
 }
 
@@ -1393,10 +1415,18 @@ check_reciprocal_kernel(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* __
 //         7.04e13 for chunks 0..63.  Quotients cover both result binades.
 // mode 2: every float divisor of the biased-exponent range [lo, hi], 64 pseudo-random numerators
 //         each with exponents 0..60 below the divisor's and random signs (scaling / sign paths).
+// mode 3: sqrt_normal against sqrtf for every positive float of the biased-exponent range.
 __global__ void __launch_bounds__(256)
 check_division_kernel(int mode, uint32_t lo, uint32_t hi, unsigned long long* __restrict__ bad) {
     unsigned long long mine = 0;
-    if (mode == 1) {
+    if (mode == 3) {   // sqrt_normal == sqrtf for every float with biased exponent in [lo, hi]
+        unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned long long total = (unsigned long long)(hi - lo + 1) << 23;
+        for (; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+            const float x = __uint_as_float(((lo + (uint32_t)(i >> 23)) << 23) | (uint32_t)(i & 0x7fffff));
+            mine += (__float_as_uint(sqrt_normal(x)) != __float_as_uint(sqrtf(x))) ? 1ull : 0ull;
+        }
+    } else if (mode == 1) {
         const unsigned long long n_div = (unsigned long long)(hi - lo + 1) << 17;
         for (unsigned long long d = blockIdx.x; d < n_div; d += gridDim.x) {
             const uint32_t mb = (lo << 17) + (uint32_t)d;

@@ -200,7 +200,9 @@ int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t *mismatches);
  * divisors 1.mb for mb in chunks [exp_lo, exp_hi] of 64 (2^17 divisors each) against ALL 2^23
  * numerator significands (chunks 0..63 = 7.04e13 pairs = every pair of significands);
  * mode 2 = every float divisor with biased exponent in [exp_lo, exp_hi], 64 pseudo-random
- * numerators each, exponents up to 60 below the divisor's, both signs. */
+ * numerators each, exponents up to 60 below the divisor's, both signs; mode 3 = the kernel's
+ * square root of normal floats (v_sqrt_f32 + neighbour residuals) against sqrtf for every positive
+ * float with biased exponent in [exp_lo, exp_hi]. */
 int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t *mismatches);
 
 /* Duration in milliseconds of the last crt_render_rows main kernel launched through this

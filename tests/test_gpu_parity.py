@@ -90,6 +90,14 @@ def test_three_instruction_quotients_are_exact(gpu, crt_built):
     assert bad.value == 0
 
 
+def test_fast_sqrt_is_exact(gpu, crt_built):
+    """len = sqrt(x*x + y*y + z*z) uses v_sqrt_f32 + the residuals of its two neighbours on the
+    guarded range: equal to sqrtf for EVERY float in 2^-100 .. 2^100."""
+    bad = C.c_uint64(123)
+    assert crt_built.crt_debug_check_division(3, 27, 227, C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 def test_unbounded_scene_uses_ieee_division_and_brute_force(gpu, oracle, crt_built):
     """Coordinates beyond 2^38: no tiling, no fast reciprocal — still the reference's pixels."""
     sc = scenes.random_soup(40, 5)
