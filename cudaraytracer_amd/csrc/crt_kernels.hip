@@ -887,6 +887,131 @@ static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int
     return hipGetLastError();
 }
 
+// ---- per-pixel candidate masks (shading kernel).  A tile's list holds every triangle some ray
+// of the 8x8 tile may hit; one pixel is hit by few of them, and a wavefront pays for a list
+// entry as soon as ONE lane needs it.  So before the sample loop each lane classifies the staged
+// entries (at most 64) against ITS pixel — the binning's rectangle test on the
+// cell [x, x+1) x [y, y+1): same forms, same slack, same arithmetic — and keeps a bit mask of
+// candidates.  Every sample then walks the lane's own candidates: the number of steps is the
+// longest per-pixel list of the wavefront instead of the tile's list.
+struct Cand {
+    unsigned lo, hi;             // bit j: staged entry j (resp. 32 + j) may be hit from this lane's pixel
+    unsigned sure_lo, sure_hi;   // ... and the cull test `dot(d, n) < 0` cannot reject it there
+};
+
+typedef float4 StageArea[4][64];   // one wavefront's LDS staging area: 4 planes x 64 entries x 16 B (plane-major:
+                                   // per-lane reads of different entries fall into different banks)
+
+// lane j < n holds list entry j (`entry`, raw pool word).  Leaves the exact records of the n
+// entries in `area` and the lane's candidate masks in `cand`.
+__device__ __forceinline__ void stage_candidates(StageArea& area, float* qw, int* ent, const RenderParams& p,
+                                                 const float4* __restrict__ cls, int n_pad,
+                                                 const float* __restrict__ rec, int entry, int n, int lane,
+                                                 int x, int y_global, Cand& cand) {
+    const float hu = (0.5f * p.rnx) * 1.00001f + 4.0e-7f + p.pos_du, hv = (0.5f * p.rny) * 1.00001f + 4.0e-7f + p.pos_dv;
+    const int t = entry & 0x7fffffff;
+    if (lane < n) {   // forms of entry `lane` as (A, B, C, q), q = radius * 1.0001 + K * M on a pixel
+        float4 f0 = cls[(size_t)0 * n_pad + t], f1 = cls[(size_t)1 * n_pad + t];
+        float4 f2 = cls[(size_t)2 * n_pad + t], f3 = cls[(size_t)3 * n_pad + t];
+        const float Bw = f1.y - f2.y - f3.y, Cw = f1.z - f2.z - f3.z, Mw = f2.w + f3.w + 1.25f * f1.w;
+        qw[lane] = __builtin_fmaf(p.K_slack, Mw, __builtin_fmaf(hv, fabsf(Cw), hu * fabsf(Bw)) * 1.0001f);
+        f0.w = __builtin_fmaf(p.K_slack, f0.w, __builtin_fmaf(hv, fabsf(f0.z), hu * fabsf(f0.y)) * 1.0001f);
+        f1.w = __builtin_fmaf(p.K_slack, f1.w, __builtin_fmaf(hv, fabsf(f1.z), hu * fabsf(f1.y)) * 1.0001f);
+        f2.w = __builtin_fmaf(p.K_slack, f2.w, __builtin_fmaf(hv, fabsf(f2.z), hu * fabsf(f2.y)) * 1.0001f);
+        f3.w = __builtin_fmaf(p.K_slack, f3.w, __builtin_fmaf(hv, fabsf(f3.z), hu * fabsf(f3.y)) * 1.0001f);
+        area[0][lane] = f0; area[1][lane] = f1; area[2][lane] = f2; area[3][lane] = f3;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float uc = ((float)x + 0.5f) * p.rnx, vc = ((float)y_global + 0.5f) * p.rny;
+    cand.lo = cand.hi = cand.sure_lo = cand.sure_hi = 0u;
+    for (int k = 0; k < n; ++k) {
+        const float4 f0 = area[0][k], f1 = area[1][k], f2 = area[2][k], f3 = area[3][k];   // broadcast reads
+        const float Aw = f1.x - f2.x - f3.x, Bw = f1.y - f2.y - f3.y, Cw = f1.z - f2.z - f3.z;
+        float c[5], q[5] = {f0.w, f1.w, f2.w, f3.w, qw[k]};
+        c[0] = __builtin_fmaf(uc, f0.y, __builtin_fmaf(vc, f0.z, f0.x));
+        c[1] = __builtin_fmaf(uc, f1.y, __builtin_fmaf(vc, f1.z, f1.x));
+        c[2] = __builtin_fmaf(uc, f2.y, __builtin_fmaf(vc, f2.z, f2.x));
+        c[3] = __builtin_fmaf(uc, f3.y, __builtin_fmaf(vc, f3.z, f3.x));
+        c[4] = __builtin_fmaf(uc, Bw, __builtin_fmaf(vc, Cw, Aw));
+        const unsigned may = cell_may_hit(c, q) ? 1u : 0u;
+        const unsigned sure = (may != 0u && c[0] > q[0]) ? 1u : 0u;   // c_dn - r_dn > S_dn
+        if (k < 32) { cand.lo |= may << k; cand.sure_lo |= sure << k; }
+        else        { cand.hi |= may << (k - 32); cand.sure_hi |= sure << (k - 32); }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n) {   // now the exact records, same slots, and the pool words (lanes may be switched off later)
+        ent[lane] = entry;
+        const float4* r = reinterpret_cast<const float4*>(rec + (size_t)t * kRecFloats);
+        area[0][lane] = r[0]; area[1][lane] = r[1]; area[2][lane] = r[2]; area[3][lane] = r[3];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exact_test_vec with a per-lane record: lanes test different triangles (or none: !active).
+template <bool FAST>
+__device__ __forceinline__ void exact_test_lane(const RecV& rc, int i, bool sure, bool active, V3 d,
+                                                float& closest, int& hit_idx) {
+    const float nx = rc.a.x, ny = rc.a.y, nz = rc.a.z;
+    const float e2x = rc.a.w, e2y = rc.b.x, e2z = rc.b.y;
+    const float e1x = rc.b.z, e1y = rc.b.w, e1z = rc.c.x;
+    const float sx = rc.c.y, sy = rc.c.z, sz = rc.c.w;
+    const float qx = rc.d.x, qy = rc.d.y, qz = rc.d.z;
+    const float tq = rc.d.w;
+
+    unsigned long long alive = __builtin_amdgcn_ballot_w64(active);
+    if (__builtin_amdgcn_ballot_w64(active && !sure) != 0ull) {
+        float dn = d.x * nx + d.y * ny + d.z * nz;                     // triangle.h:61
+        alive &= __builtin_amdgcn_ballot_w64(sure || !(dn < 0.0f));
+        if (alive == 0ull) return;
+    }
+    float hx = (d.y * e2z - d.z * e2y);                               // triangle.h:71-72
+    float hy = (-(d.x * e2z - d.z * e2x));
+    float hz = (d.x * e2y - d.y * e2x);
+    float a = e1x * hx + e1y * hy + e1z * hz;
+    alive &= __builtin_amdgcn_ballot_w64(!(fabsf(a) < kTriEpsilon));  // triangle.h:77
+    if (alive == 0ull) return;
+    float f = reciprocal<FAST>(a);                                    // triangle.h:80
+    float u = f * (sx * hx + sy * hy + sz * hz);                      // triangle.h:82
+    alive &= __builtin_amdgcn_ballot_w64(!(u < 0.0f)) & __builtin_amdgcn_ballot_w64(!(u > 1.0f));   // triangle.h:84
+    if (alive == 0ull) return;
+    float v = f * (d.x * qx + d.y * qy + d.z * qz);                   // triangle.h:88
+    alive &= __builtin_amdgcn_ballot_w64(!(v < 0.0f)) & __builtin_amdgcn_ballot_w64(!(u + v > 1.0f));   // triangle.h:89
+    if (alive == 0ull) return;
+    float t = f * tq;                                                 // triangle.h:92
+    if (__builtin_amdgcn_inverse_ballot_w64(alive) && (t < closest || (t == closest && i < hit_idx))) {  // hitable_list.h:84, order-independent
+        closest = t;
+        hit_idx = i;
+    }
+}
+
+// one sample of one lane against its candidates
+__device__ __forceinline__ void trace_candidates(StageArea& area, const int* ent, const Cand& cand, V3 d2,
+                                                 float& closest, int& hit_idx) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        unsigned m = half ? cand.hi : cand.lo;
+        const unsigned sm = half ? cand.sure_hi : cand.sure_lo;
+        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+            const bool active = m != 0u;
+            const int j = active ? __builtin_ctz(m) : 0;
+            const bool sure = ((sm >> j) & 1u) != 0u;
+            m &= m - 1u;
+            const int k = half * 32 + j;
+            const int e = ent[k];
+            RecV rc;
+            rc.a = area[0][k];
+            rc.b = area[1][k];
+            rc.c = area[2][k];
+            rc.d = area[3][k];
+            exact_test_lane<true>(rc, e & 0x7fffffff, sure || e < 0, active, d2, closest, hit_idx);
+        }
+    }
+}
+
 // (t, index) as one 64-bit key whose unsigned order is the reference's accept order: smaller t
 // first (IEEE order of non-NaN floats; -0 is folded into +0 because the reference's `<` does not
 // separate them), lower triangle index on equal t (hitable_list.h:84 walks in index order with
@@ -906,13 +1031,15 @@ __device__ __forceinline__ unsigned long long hit_key(float t, int idx) {
 // one per wave.
 template <bool VREC, int OCC, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
-shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* __restrict__ shade_n,
-                   uint32_t* __restrict__ state, float* __restrict__ rgb, TiledWork w,
-                   unsigned long long* __restrict__ stats, int dbg_repeat) {
+shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
+                   const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
+                   TiledWork w, unsigned long long* __restrict__ stats, int dbg_repeat) {
     __shared__ unsigned long long best_key[64];   // per pixel: min over the waves of (ordered t, index)
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
-    __shared__ float4 lrec[VREC ? WAVES : 1][64][4];   // light tiles: this wave's survivor records (4 KB per wave)
+    __shared__ StageArea lrec[VREC ? WAVES : 1];       // this wave's staged list entries: forms, then exact records (4 KB per wave)
+    __shared__ float lqw[VREC ? WAVES : 1][64];        // slack + radius of the fifth form of the staged entries
+    __shared__ int lent[VREC ? WAVES : 1][64];         // pool words of the staged entries
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -954,30 +1081,15 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
             // this wave's slice: the first 64 entries are staged in LDS like a light tile's list
             const int n_lds = (VREC && !walk_all) ? min(64, k1 - k0) : 0;
             int slice_mine = 0;
-            if (n_lds > 0) {
+            Cand cand = {0u, 0u, 0u, 0u};
+            if (n_lds > 0) {   // per-pixel candidates among the staged entries of this wave's slice
                 slice_mine = (lane < n_lds) ? (int)lst[k0 + lane] : 0;
-                if (lane < n_lds) {
-                    const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(slice_mine & 0x7fffffff) * kRecFloats);
-                    lrec[wave][lane][0] = r[0];
-                    lrec[wave][lane][1] = r[1];
-                    lrec[wave][lane][2] = r[2];
-                    lrec[wave][lane][3] = r[3];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
+                                 global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
             }
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
-                for (int k = 0; k < n_lds; ++k) {
-                    RecV rc;
-                    rc.a = lrec[wave][k][0];
-                    rc.b = lrec[wave][k][1];
-                    rc.c = lrec[wave][k][2];
-                    rc.d = lrec[wave][k][3];
-                    asm volatile("" : "+v"(rc.a.x), "+v"(rc.a.w), "+v"(rc.b.x), "+v"(rc.b.w), "+v"(rc.c.x), "+v"(rc.c.w), "+v"(rc.d.x), "+v"(rc.d.w));
-                    exact_test_vec<true>(rc, __builtin_amdgcn_readlane(slice_mine, k), d2, closest, hit_idx);
-                }
+                if (n_lds > 0) trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
                 if (!walk_all) walk_list<true>(rec, lst, k0 + n_lds, k1, lane, d2, closest, hit_idx);
                 else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
               }
@@ -1079,17 +1191,25 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
         // the whole list of a light tile fits one or two VGPRs (lane j holds positions j, 64+j)
         const int mine0 = (lane < cnt) ? (int)lst[lane] : 0;
         const int mine1 = (64 + lane < cnt) ? (int)lst[64 + lane] : 0;
-        if (VREC) {   // stage the records of the list in this wave's LDS area (all 64 lanes, before any lane leaves)
-            if (lane < min(cnt, 64)) {
-                const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(mine0 & 0x7fffffff) * kRecFloats);
-                lrec[wave][lane][0] = r[0];
-                lrec[wave][lane][1] = r[1];
-                lrec[wave][lane][2] = r[2];
-                lrec[wave][lane][3] = r[3];
+        const int n0 = min(cnt, 64);
+        Cand cand = {0u, 0u, 0u, 0u};
+        if (VREC && cnt > 0)   // all 64 lanes, before any lane leaves: lanes off the image classify a valid pixel
+            stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, n0, lane, min(x, p.nx - 1),
+                             global_row(p.row_begin, p.strip_rows, p.strip_step, min(ly, p.row_count - 1)), cand);
+        if (stats && VREC && cnt > 0) {   // diagnostics: per-pixel candidates vs the tile's list
+            const unsigned pc = (unsigned)(__builtin_popcount(cand.lo) + __builtin_popcount(cand.hi));
+            unsigned mx = pc, sm = pc;
+#pragma unroll
+            for (int ofs = 32; ofs > 0; ofs >>= 1) {
+                mx = max(mx, (unsigned)__shfl_xor((int)mx, ofs, 64));
+                sm += (unsigned)__shfl_xor((int)sm, ofs, 64);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0) {
+                atomicAdd(&stats[37], 1ull);
+                atomicAdd(&stats[38], (unsigned long long)cnt);
+                atomicAdd(&stats[39], (unsigned long long)mx);
+                atomicAdd(&stats[40], (unsigned long long)sm);
+            }
         }
         if (cnt == 0) {   // background only (most tiles of a typical frame)
             if (x < p.nx && ly < p.row_count)
@@ -1099,17 +1219,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float* _
                          [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (VREC) {
-                    const int n0 = min(cnt, 64);
-                    for (int k = 0; k < n0; ++k) {
-                        RecV rc;
-                        rc.a = lrec[wave][k][0];
-                        rc.b = lrec[wave][k][1];
-                        rc.c = lrec[wave][k][2];
-                        rc.d = lrec[wave][k][3];
-                        // consumed together: four broadcast ds_read_b128 in flight, one wait
-                        asm volatile("" : "+v"(rc.a.x), "+v"(rc.a.w), "+v"(rc.b.x), "+v"(rc.b.w), "+v"(rc.c.x), "+v"(rc.c.w), "+v"(rc.d.x), "+v"(rc.d.w));
-                        exact_test_vec<true>(rc, __builtin_amdgcn_readlane(mine0, k), d2, closest, hit_idx);
-                    }
+                    trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
                     walk<true>(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
                 } else {
                     walk<true>(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
@@ -1259,7 +1369,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     TiledWork w = *work;
     if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
     int heavy = (variant == 2) ? 3 : kHeavyMin;          // tiles with more survivors are shared by all waves
-    if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::min(atoi(e), 128);   // tuning hooks (not part of the ABI)
+    if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::min(atoi(e), 64);   // tuning hooks (not part of the ABI)
     // Waves that share a heavy tile: 8 when the launch has plenty of tiles per CU (throughput),
     // 16 when it is small (a rank of a multi-GPU split): then the longest tile bounds the time.
     int dbg_repeat = 1, group = (w.tiles_total >= n_cus * 96) ? 8 : 16;
@@ -1269,7 +1379,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* e = getenv("CRT_DEBUG_WALK_REPEAT")) dbg_repeat = atoi(e);   // timing experiments only
     bool vrec = variant != 3;   // light tiles: records staged in LDS (VGPR operands); variant 3 keeps the scalar-operand walk (A/B)
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
-    using ShadeFn = void (*)(RenderParams, const float*, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int);
+    using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int);
     ShadeFn fn;
     if (group == 8) {
         occ = (occ == 6 || occ == 4) ? occ : 8;
@@ -1294,8 +1404,8 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         e = hipEventRecord(ev_mid, stream);   // splits the timing: [start, mid) = binning, [mid, stop) = shading
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)n_blocks), dim3((unsigned)group * 64), 0, stream, p, d_rec, d_shade_n, d_state,
-                       d_rgb, w, d_stats, dbg_repeat);
+    hipLaunchKernelGGL(fn, dim3((unsigned)n_blocks), dim3((unsigned)group * 64), 0, stream, p, d_rec, d_cls, n_pad, d_shade_n,
+                       d_state, d_rgb, w, d_stats, dbg_repeat);
     return hipGetLastError();
 }
 
