@@ -603,7 +603,7 @@ constexpr unsigned kCullSureBit = 0x80000000u;   // pool entry flag: the cull te
 constexpr int kRegionW = 128, kRegionH = 32;
 constexpr int kRegionTilesX = kRegionW / 8, kRegionTilesY = kRegionH / 8;
 constexpr int kBinThreads = 64;
-constexpr int kBinWavesMin = 4096;   // the screen is cut into slices of region rows (blockIdx.y) / columns (blockIdx.z)
+constexpr int kBinWavesMin = 16384;   // the screen is cut into slices of region rows (blockIdx.y) / columns (blockIdx.z)
                                      // until the launch has this many wavefronts: few large triangles are not one wave's work
 constexpr int kFewTriangles = 16;    // a region with at most this many candidates is classified lane = tile
 
@@ -877,8 +877,10 @@ static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int
     if (e != hipSuccess) return e;
     const int region_nx = (w.tiles_x + kRegionTilesX - 1) / kRegionTilesX, region_ny = (w.tiles_y + kRegionTilesY - 1) / kRegionTilesY;
     const int n_waves = (p.n_tris + kBinThreads - 1) / kBinThreads;
-    const int slices_y = std::max(1, std::min(region_ny, kBinWavesMin / std::max(n_waves, 1)));
-    const int slices_x = std::max(1, std::min(region_nx, kBinWavesMin / std::max(n_waves * slices_y, 1)));
+    int waves_min = kBinWavesMin;
+    if (const char* ev = getenv("CRT_BIN_WAVES")) waves_min = std::max(1, atoi(ev));   // tuning hook
+    const int slices_y = std::max(1, std::min(region_ny, waves_min / std::max(n_waves, 1)));
+    const int slices_x = std::max(1, std::min(region_nx, waves_min / std::max(n_waves * slices_y, 1)));
     const dim3 grid_tri((unsigned)n_waves, (unsigned)slices_y, (unsigned)slices_x);
     if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<0>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats);
     hipLaunchKernelGGL(bin_alloc_kernel, dim3((unsigned)((w.tiles_total + kAllocThreads - 1) / kAllocThreads)), dim3(kAllocThreads), 0, stream, w,
