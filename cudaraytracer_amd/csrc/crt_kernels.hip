@@ -579,6 +579,7 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
 // the reference's float evaluation can commit (DESIGN.md §4.4 has the derivation).
 //   binning (lane = triangle) -> per-tile survivor lists; shading (lane = pixel) -> the reference
 //   arithmetic (exact_test) on the tile's survivors only.
+constexpr int kHeavyMinSmall = 16, kHeavyMinMedium = 24;   // same for small launches (< 24 / < 96 tiles per CU)
 constexpr int kHeavyMin = 48;  // tiles with more survivors than this are traced by all waves of a block together (measured optimum, 12..64 swept)
 constexpr unsigned kNoList = 0xffffffffu;   // tile_desc.y: the pool was full, walk every triangle
 constexpr unsigned kCullSureBit = 0x80000000u;   // pool entry flag: the cull test cannot reject in this tile
@@ -1370,15 +1371,19 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     }
     TiledWork w = *work;
     if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
-    int heavy = (variant == 2) ? 3 : kHeavyMin;          // tiles with more survivors are shared by all waves
-    if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::min(atoi(e), 64);   // tuning hooks (not part of the ABI)
     // Waves that share a heavy tile: 8 when the launch has plenty of tiles per CU (throughput),
-    // 16 when it is small (a rank of a multi-GPU split): then the longest tile bounds the time.
-    int dbg_repeat = 1, group = (w.tiles_total >= n_cus * 96) ? 8 : 16;
+    // 16 when it is small (a rank of a multi-GPU split): then the 64-sample chain of the densest
+    // tile bounds the time, so more tiles are shared (lower threshold) by more waves.
+    const int tiles_per_cu = w.tiles_total / std::max(n_cus, 1);
+    int dbg_repeat = 1, group = (tiles_per_cu >= 24) ? 8 : 16;
     int occ = (group == 8) ? 6 : 8;   // measured optimum with the LDS-staged light tiles
-    if (const char* e = getenv("CRT_SHADE_OCC")) occ = atoi(e);
+    if (const char* e = getenv("CRT_SHADE_OCC")) occ = atoi(e);                  // tuning hooks (not part of the ABI)
     if (const char* e = getenv("CRT_SHADE_GROUP")) group = atoi(e);              // waves that share a heavy tile
     if (const char* e = getenv("CRT_DEBUG_WALK_REPEAT")) dbg_repeat = atoi(e);   // timing experiments only
+    // tiles with more survivors than this are shared by all waves of a block (measured: a full frame, and one
+    // rank's strips of a 2-, 4-, 8-way split on the bench scene)
+    int heavy = (variant == 2) ? 3 : (tiles_per_cu >= 96 ? kHeavyMin : (tiles_per_cu >= 24 ? kHeavyMinMedium : kHeavyMinSmall));
+    if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::min(atoi(e), 64);
     bool vrec = variant != 3;   // light tiles: records staged in LDS (VGPR operands); variant 3 keeps the scalar-operand walk (A/B)
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
     using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int);

@@ -19,3 +19,9 @@ for r in range(min(world, 3)):
     o = api.tiled_stats(False)
     print("rank %d: total %.3f bin %.3f shade %.3f ms | tiles %d sum2 %d max2 %d | hist %s" % (r, t[0], t[1], t[2], o[4], o[5], o[6], o[8:20]))
     print("   shade cycles: heavy sum/blocks %d max %d | light sum/waves %d max %d | max wave total %d" % tuple(o[24:29]))
+    print("   heavy tiles %d (sum survivors %d): master cycles per tile: setup+merge+shade %.0f, own trace %.0f, wait B2 %.0f" % (o[35], o[36], o[32]/max(o[35],1), o[33]/max(o[35],1), o[34]/max(o[35],1)))
+    br2 = BandRenderer(scene, cam, bench.NX, bench.NY, r, world, mode="strips")
+    ts = []
+    for _ in range(5):
+        br2.render(64); torch.cuda.synchronize(); ts.append(api.last_kernel_times())
+    print("   without stats: total/bin/shade ms", min(ts))
