@@ -58,12 +58,13 @@ def algorithmic_bytes_tiled(nx, rows, spp, n_tris, base_bytes, sum2):
     reads the base record and writes the 64-B exact record, cls_prepass reads it and writes the
     80-B classification record, the count and the fill pass of bin_tri_kernel read that once
     each; every list entry is written once (4 B), every tile has a count and a descriptor (12 B).
-    shade kernel: every (tile, sample) reads the 64-B exact record of each of the tile's
-    survivors, the list once per tile, plus framebuffer + RNG state."""
+    shade kernel: every tile reads, once, the list entry (4 B), the 64-B classification forms and the
+    64-B exact record of each of its survivors (staged in LDS for all samples), plus the float3
+    store (12 B) and the XORWOW state load/store (48 B) per pixel."""
     px = nx * rows
     tiles = ((nx + 7) // 8) * ((rows + 7) // 8)
     bin_b = n_tris * (base_bytes + REC_BYTES + REC_BYTES + CLS_BYTES + 2 * CLS_BYTES) + sum2 * 4 + tiles * 12
-    shade_b = spp * sum2 * REC_BYTES + sum2 * 4 + px * 12 + px * 48
+    shade_b = sum2 * (4 + 64 + REC_BYTES) + tiles * 8 + px * 12 + px * 48
     return bin_b, shade_b
 
 
@@ -207,7 +208,7 @@ def main():
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this very
         # command (tools/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
         traffic, traffic_src, valu = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r1_tiled", "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin"))
+        pmc = os.path.join(ROOT, "profiles", "r1_tiled", "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin_fill"))
         if tiled and world == 1 and args.spp == SPP and os.path.exists(pmc):
             try:
                 summary = json.load(open(pmc))

@@ -160,21 +160,25 @@ int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
 
 /* Kernel selection (diagnostics / A-B benchmarking), per calling thread. 0 = auto (default:
  * tiled when the scene and camera are finite and |coordinate| <= 2^38, else brute force),
- * 1 = brute-force list walk, 2 = tiled, 3 = tiled with tiny survivor-list capacities (test
- * hook for the overflow fallbacks), 4 = tiled with scalar-operand (SGPR) triangle records
- * also for light tiles instead of the LDS-staged VGPR records (A/B).  All variants produce identical pixels.  Returns the previous value. */
+ * 1 = brute-force list walk, 2 = tiled, 3 = tiled with a tiny survivor pool and heavy-tile
+ * threshold (test hook for the overflow fallback and the shared-tile path), 4 = tiled with
+ * scalar-operand (SGPR) list walks instead of the LDS-staged records and per-pixel candidate
+ * masks (A/B).  All variants produce identical pixels.  Returns the previous value. */
 int crt_set_kernel_variant(int variant);
 
 /* Diagnostics of the tiled variant, per calling thread.  out48 (nullable, 48 words) first
  * receives the counters accumulated since the last enable:
- *   [0] regions, [1] sum and [2] max of the region survivor count, [3] region-list overflows,
+ *   binning: [0] wavefronts that found work, [1] regions they entered, [2] tiles box-tested
+ *   (64 per triangle and region in the lane = tile mode), [3] (wavefront, tile) pairs with survivors,
  *   [4] tiles, [5] sum and [6] max of the tile survivor count, [7] pool overflows,
  *   [8..23] histogram of the tile survivor count (bucket b: 2^(b-1) <= n < 2^b),
  *   shading kernel cycles (s_memtime): [24] heavy phase summed over blocks, [25] its max,
  *   [26] light phase summed over waves, [27] its max, [28] max wave total,
- *   binning kernel cycles: [29] phase A summed over blocks, [30] its max, [31] slowest wave of
- *   phase A2; master wave of shared tiles: [32] set-up+merge+shade, [33] own trace, [34] wait
- *   at the second barrier (cycles summed over [35] tiles with [36] survivors in total).
+ *   busiest binning wavefront: [29] regions entered, [30] tiles box-tested, [31] cycles;
+ *   master wave of shared tiles: [32] set-up+merge+shade, [33] own trace, [34] wait at the
+ *   second barrier (cycles summed over [35] tiles with [36] survivors in total);
+ *   per-pixel candidate masks of the light tiles with geometry: [37] tiles, [38] their list
+ *   entries, [39] sum of the longest per-pixel candidate list of each, [40] sum of all lists.
  * Then enable != 0 (re)starts counting, enable == 0 stops it.  Counting costs a few atomics
  * and clock reads per wavefront. */
 int crt_debug_tiled_stats(int enable, uint64_t *out48);
