@@ -905,41 +905,63 @@ struct Cand {
 typedef float4 StageArea[4][64];   // one wavefront's LDS staging area: 4 planes x 64 entries x 16 B (plane-major:
                                    // per-lane reads of different entries fall into different banks)
 
+// q = radius * 1.0001 + K * M of one form on a 1-pixel cell (hu, hv: pixel half extents incl. position slack)
+__device__ __forceinline__ float pixel_q(float K, float hu, float hv, float B, float C, float M) {
+    return __builtin_fmaf(K, M, __builtin_fmaf(hv, fabsf(C), hu * fabsf(B)) * 1.0001f);
+}
+__device__ __forceinline__ void pixel_half_extents(const RenderParams& p, float& hu, float& hv) {
+    hu = (0.5f * p.rnx) * 1.00001f + 4.0e-7f + p.pos_du;
+    hv = (0.5f * p.rny) * 1.00001f + 4.0e-7f + p.pos_dv;
+}
+// The rectangle test on the pixel (x, y_global) from forms stored as (A, B, C, q); q4 = q of w.
+__device__ __forceinline__ bool pixel_may_hit(const RenderParams& p, float4 f0, float4 f1, float4 f2, float4 f3, float q4,
+                                              int x, int y_global, bool& sure) {
+    const float uc = ((float)x + 0.5f) * p.rnx, vc = ((float)y_global + 0.5f) * p.rny;
+    const float Aw = f1.x - f2.x - f3.x, Bw = f1.y - f2.y - f3.y, Cw = f1.z - f2.z - f3.z;
+    float c[5], q[5] = {f0.w, f1.w, f2.w, f3.w, q4};
+    c[0] = __builtin_fmaf(uc, f0.y, __builtin_fmaf(vc, f0.z, f0.x));
+    c[1] = __builtin_fmaf(uc, f1.y, __builtin_fmaf(vc, f1.z, f1.x));
+    c[2] = __builtin_fmaf(uc, f2.y, __builtin_fmaf(vc, f2.z, f2.x));
+    c[3] = __builtin_fmaf(uc, f3.y, __builtin_fmaf(vc, f3.z, f3.x));
+    c[4] = __builtin_fmaf(uc, Bw, __builtin_fmaf(vc, Cw, Aw));
+    const bool may = cell_may_hit(c, q);
+    sure = may && c[0] > q[0];   // c_dn - r_dn > S_dn
+    return may;
+}
+// (A, B, C, M) records of the four forms -> (A, B, C, q) on a pixel; returns q of the fifth form
+__device__ __forceinline__ float pixel_forms(const RenderParams& p, float4& f0, float4& f1, float4& f2, float4& f3) {
+    float hu, hv;
+    pixel_half_extents(p, hu, hv);
+    const float Bw = f1.y - f2.y - f3.y, Cw = f1.z - f2.z - f3.z, Mw = f2.w + f3.w + 1.25f * f1.w;
+    const float q4 = pixel_q(p.K_slack, hu, hv, Bw, Cw, Mw);
+    f0.w = pixel_q(p.K_slack, hu, hv, f0.y, f0.z, f0.w);
+    f1.w = pixel_q(p.K_slack, hu, hv, f1.y, f1.z, f1.w);
+    f2.w = pixel_q(p.K_slack, hu, hv, f2.y, f2.z, f2.w);
+    f3.w = pixel_q(p.K_slack, hu, hv, f3.y, f3.z, f3.w);
+    return q4;
+}
+
 // lane j < n holds list entry j (`entry`, raw pool word).  Leaves the exact records of the n
 // entries in `area` and the lane's candidate masks in `cand`.
 __device__ __forceinline__ void stage_candidates(StageArea& area, float* qw, int* ent, const RenderParams& p,
                                                  const float4* __restrict__ cls, int n_pad,
                                                  const float* __restrict__ rec, int entry, int n, int lane,
                                                  int x, int y_global, Cand& cand) {
-    const float hu = (0.5f * p.rnx) * 1.00001f + 4.0e-7f + p.pos_du, hv = (0.5f * p.rny) * 1.00001f + 4.0e-7f + p.pos_dv;
     const int t = entry & 0x7fffffff;
     if (lane < n) {   // forms of entry `lane` as (A, B, C, q), q = radius * 1.0001 + K * M on a pixel
         float4 f0 = cls[(size_t)0 * n_pad + t], f1 = cls[(size_t)1 * n_pad + t];
         float4 f2 = cls[(size_t)2 * n_pad + t], f3 = cls[(size_t)3 * n_pad + t];
-        const float Bw = f1.y - f2.y - f3.y, Cw = f1.z - f2.z - f3.z, Mw = f2.w + f3.w + 1.25f * f1.w;
-        qw[lane] = __builtin_fmaf(p.K_slack, Mw, __builtin_fmaf(hv, fabsf(Cw), hu * fabsf(Bw)) * 1.0001f);
-        f0.w = __builtin_fmaf(p.K_slack, f0.w, __builtin_fmaf(hv, fabsf(f0.z), hu * fabsf(f0.y)) * 1.0001f);
-        f1.w = __builtin_fmaf(p.K_slack, f1.w, __builtin_fmaf(hv, fabsf(f1.z), hu * fabsf(f1.y)) * 1.0001f);
-        f2.w = __builtin_fmaf(p.K_slack, f2.w, __builtin_fmaf(hv, fabsf(f2.z), hu * fabsf(f2.y)) * 1.0001f);
-        f3.w = __builtin_fmaf(p.K_slack, f3.w, __builtin_fmaf(hv, fabsf(f3.z), hu * fabsf(f3.y)) * 1.0001f);
+        qw[lane] = pixel_forms(p, f0, f1, f2, f3);
         area[0][lane] = f0; area[1][lane] = f1; area[2][lane] = f2; area[3][lane] = f3;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const float uc = ((float)x + 0.5f) * p.rnx, vc = ((float)y_global + 0.5f) * p.rny;
     cand.lo = cand.hi = cand.sure_lo = cand.sure_hi = 0u;
     for (int k = 0; k < n; ++k) {
-        const float4 f0 = area[0][k], f1 = area[1][k], f2 = area[2][k], f3 = area[3][k];   // broadcast reads
-        const float Aw = f1.x - f2.x - f3.x, Bw = f1.y - f2.y - f3.y, Cw = f1.z - f2.z - f3.z;
-        float c[5], q[5] = {f0.w, f1.w, f2.w, f3.w, qw[k]};
-        c[0] = __builtin_fmaf(uc, f0.y, __builtin_fmaf(vc, f0.z, f0.x));
-        c[1] = __builtin_fmaf(uc, f1.y, __builtin_fmaf(vc, f1.z, f1.x));
-        c[2] = __builtin_fmaf(uc, f2.y, __builtin_fmaf(vc, f2.z, f2.x));
-        c[3] = __builtin_fmaf(uc, f3.y, __builtin_fmaf(vc, f3.z, f3.x));
-        c[4] = __builtin_fmaf(uc, Bw, __builtin_fmaf(vc, Cw, Aw));
-        const unsigned may = cell_may_hit(c, q) ? 1u : 0u;
-        const unsigned sure = (may != 0u && c[0] > q[0]) ? 1u : 0u;   // c_dn - r_dn > S_dn
+        bool sure_b;
+        const unsigned may = pixel_may_hit(p, area[0][k], area[1][k], area[2][k], area[3][k], qw[k], x, y_global, sure_b) ? 1u : 0u;   // broadcast reads
+        const unsigned sure = sure_b ? 1u : 0u;
         if (k < 32) { cand.lo |= may << k; cand.sure_lo |= sure << k; }
         else        { cand.hi |= may << (k - 32); cand.sure_hi |= sure << (k - 32); }
     }
@@ -1422,8 +1444,8 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
 // see dn < 0.  counters: [0] passing pairs, [1] pairs missing from the list, [2] cull-sure
 // violations, [3] first offender (tile << 32 | triangle).
 __global__ void __launch_bounds__(256)
-audit_tiles_kernel(RenderParams p, const float* __restrict__ rec, const uint32_t* __restrict__ state,
-                   TiledWork w, unsigned long long* __restrict__ counters) {
+audit_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
+                   const uint32_t* __restrict__ state, TiledWork w, unsigned long long* __restrict__ counters) {
     __shared__ volatile uint32_t member[4][64], sure_of[4][64];   // per wavefront: 2048-bit windows of the tile's list
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1484,6 +1506,18 @@ audit_tiles_kernel(RenderParams p, const float* __restrict__ rec, const uint32_t
                 const bool sure = ((sure_of[wave][rel >> 5] >> (rel & 31)) & 1u) != 0u;
                 const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass);
                 n_pass += (unsigned long long)__builtin_popcountll(mp);
+                if (mp != 0ull && cls != nullptr) {   // the shading kernel's per-pixel masks must keep the pair too
+                    float4 f0 = cls[(size_t)0 * n_pad + i], f1 = cls[(size_t)1 * n_pad + i];
+                    float4 f2 = cls[(size_t)2 * n_pad + i], f3 = cls[(size_t)3 * n_pad + i];
+                    const float q4 = pixel_forms(p, f0, f1, f2, f3);
+                    bool sure_px;
+                    const bool may_px = pixel_may_hit(p, f0, f1, f2, f3, q4, x, y, sure_px);
+                    const unsigned long long miss_px = __builtin_amdgcn_ballot_w64(pass && !may_px);
+                    const unsigned long long cull_px = __builtin_amdgcn_ballot_w64(sure_px && dn < 0.0f);
+                    n_miss += (unsigned long long)__builtin_popcountll(miss_px);
+                    n_cull += (unsigned long long)__builtin_popcountll(cull_px);
+                    if (miss_px != 0ull && lane == 0) atomicMax(&counters[3], ((unsigned long long)tile_id << 32) | (unsigned long long)i);
+                }
                 if (mp != 0ull && !in_list) {
                     n_miss += (unsigned long long)__builtin_popcountll(mp);
                     if (lane == 0) atomicMax(&counters[3], ((unsigned long long)tile_id << 32) | (unsigned long long)i);
@@ -1507,7 +1541,7 @@ hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4*
     hipError_t e = launch_binning(p, d_cls, n_pad, w, kHeavyMin, 0u, nullptr, stream);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)((w.tiles_x + 1) / 2), (unsigned)((w.tiles_y + 1) / 2));
-    hipLaunchKernelGGL(audit_tiles_kernel, grid, dim3(256), 0, stream, p, d_rec, d_state, w, d_counters);
+    hipLaunchKernelGGL(audit_tiles_kernel, grid, dim3(256), 0, stream, p, d_rec, d_cls, n_pad, d_state, w, d_counters);
     return hipGetLastError();
 }
 

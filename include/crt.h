@@ -186,9 +186,11 @@ int crt_debug_tiled_stats(int enable, uint64_t *out48);
 /* Audit of the tiled variant's binning (full nx x ny image on the current device): a brute-
  * force kernel tests every triangle against `samples` rays of every pixel (pixel-corner jitter
  * included) and checks that each (ray, triangle) pair passing Triangle::collision_detection —
- * closest hit or not — has its triangle in the tile's survivor list.  out4[0] = passing pairs
- * seen, out4[1] = pairs whose triangle is missing (must be 0), out4[2] = "cull-sure" entries
- * that saw dot(d, normal) < 0 (must be 0), out4[3] = last offender (tile << 32 | triangle). */
+ * closest hit or not — has its triangle in the tile's survivor list AND passes the shading
+ * kernel's per-pixel candidate test for its pixel.  out4[0] = passing pairs seen, out4[1] = pairs
+ * whose triangle is missing from the list or from the pixel's candidates (must be 0), out4[2] =
+ * "cull-sure" verdicts (tile or pixel) that saw dot(d, normal) < 0 (must be 0), out4[3] = last
+ * offender (tile << 32 | triangle). */
 int crt_debug_audit_tiles(const crt_scene *scene, const crt_camera *camera, int nx, int ny,
                           int samples, uint64_t seed, uint64_t *out4);
 
