@@ -1421,9 +1421,15 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
                   : (occ == 4 ? shade_tiles_kernel<false, 4, 16> : shade_tiles_kernel<false, 8, 16>);
     }
     // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b)
-    int resident = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, fn, group * 64, 0);
-    if (e != hipSuccess) return e;
+    static thread_local ShadeFn cached_fn = nullptr;
+    static thread_local int cached_resident = 0;
+    hipError_t e = hipSuccess;
+    if (cached_fn != fn) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&cached_resident, fn, group * 64, 0);
+        if (e != hipSuccess) return e;
+        cached_fn = fn;
+    }
+    const int resident = cached_resident;
     int n_blocks = n_cus * std::max(resident, 1);
     if (const char* ev = getenv("CRT_SHADE_GRID")) n_blocks = std::max(1, atoi(ev));
     n_blocks = std::max(1, std::min(n_blocks, w.tiles_total));

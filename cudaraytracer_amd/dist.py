@@ -40,20 +40,33 @@ def partition_strips(ny, world_size, rank, strip_rows=STRIP_ROWS):
     return out
 
 
-def _gather_padded(piece, max_elems, rank, world_size, group):
+class _GatherBuffers:
+    """Persistent staging of one split: this rank's padded piece and, on rank 0, one [W, max]
+    buffer whose rows are the gather targets (no allocation and no padding copy per frame)."""
+
+    def __init__(self, max_elems, rank, world_size, like):
+        self.max_elems = max_elems
+        self.send = like.new_zeros(max_elems)
+        self.recv = like.new_empty((world_size, max_elems)) if (rank == 0 and world_size > 1) else None
+
+
+def _gather_padded(piece, max_elems, rank, world_size, group, bufs=None):
+    """dist.gather of equally sized (padded) pieces; returns the [W, max_elems] buffer on rank 0."""
     if piece.is_cuda and dist.get_backend(group) == "gloo":
         piece = piece.cpu()          # rehearsal on a shared GPU: gloo has no device gather
-    padded = piece.new_zeros(max_elems)
-    padded[: piece.numel()] = piece.reshape(-1)
+        bufs = None
+    if bufs is None or bufs.send.device != piece.device:
+        bufs = _GatherBuffers(max_elems, rank, world_size, piece)
+    if piece.data_ptr() != bufs.send.data_ptr():      # BandRenderer renders straight into bufs.send
+        bufs.send[: piece.numel()] = piece.reshape(-1)
     if rank == 0:
-        parts = [torch.empty_like(padded) for _ in range(world_size)]
-        dist.gather(padded, gather_list=parts, dst=0, group=group)
-        return parts
-    dist.gather(padded, gather_list=None, dst=0, group=group)
+        dist.gather(bufs.send, gather_list=[bufs.recv[r] for r in range(world_size)], dst=0, group=group)
+        return bufs.recv
+    dist.gather(bufs.send, gather_list=None, dst=0, group=group)
     return None
 
 
-def gather_framebuffer(band, nx, ny, rank, world_size, group=None):
+def gather_framebuffer(band, nx, ny, rank, world_size, group=None, bufs=None):
     """Contiguous bands: gather every rank's band (float32 tensor, count*nx*3 elements, any
     device) on rank 0.  Returns the full [ny, nx, 3] tensor on rank 0 and None elsewhere.
     One collective: torch.distributed.gather of equally sized (padded) pieces —
@@ -61,31 +74,36 @@ def gather_framebuffer(band, nx, ny, rank, world_size, group=None):
     if world_size == 1:
         return band.reshape(ny, nx, 3)
     max_rows = partition_rows(ny, world_size, 0)[1]
-    parts = _gather_padded(band, max_rows * nx * 3, rank, world_size, group)
+    parts = _gather_padded(band, max_rows * nx * 3, rank, world_size, group, bufs)
     if parts is None:
         return None
-    full = band.new_empty(ny * nx * 3)
+    full = parts.new_empty(ny * nx * 3)
     for r in range(world_size):
         b, c = partition_rows(ny, world_size, r)
         full[b * nx * 3:(b + c) * nx * 3] = parts[r][: c * nx * 3]
     return full.reshape(ny, nx, 3)
 
 
-def gather_strips(piece, nx, ny, rank, world_size, strip_rows=STRIP_ROWS, group=None):
-    """Round-robin strips: `piece` holds this rank's strips one after the other.  One gather,
-    then rank 0 copies every strip to its place."""
+def gather_strips(piece, nx, ny, rank, world_size, strip_rows=STRIP_ROWS, group=None, bufs=None):
+    """Round-robin strips: `piece` holds this rank's strips one after the other.  One gather;
+    rank 0 then puts all complete rounds of strips in place with ONE strided copy
+    (full[g, r] = parts[r, g] for round g, rank r) and the ragged last round strip by strip."""
     if world_size == 1:
         return piece.reshape(ny, nx, 3)
     rows_of = [sum(c for _, c in partition_strips(ny, world_size, r, strip_rows)) for r in range(world_size)]
-    parts = _gather_padded(piece, max(rows_of) * nx * 3, rank, world_size, group)
+    parts = _gather_padded(piece, max(rows_of) * nx * 3, rank, world_size, group, bufs)
     if parts is None:
         return None
-    full = piece.new_empty(ny, nx, 3)
-    for r in range(world_size):
-        p = parts[r][: rows_of[r] * nx * 3].reshape(rows_of[r], nx, 3)
-        at = 0
-        for y0, c in partition_strips(ny, world_size, r, strip_rows):
-            full[y0:y0 + c] = p[at:at + c]
+    full = parts.new_empty(ny, nx, 3)
+    strip_elems = strip_rows * nx * 3
+    rounds = ny // (strip_rows * world_size)               # rounds in which every rank has a full strip
+    if rounds > 0:
+        dst = full.reshape(-1)[: rounds * world_size * strip_elems].view(rounds, world_size, strip_elems)
+        dst.copy_(parts[:, : rounds * strip_elems].view(world_size, rounds, strip_elems).transpose(0, 1))
+    for r in range(world_size):                             # the last, incomplete round
+        at = rounds * strip_rows
+        for y0, c in partition_strips(ny, world_size, r, strip_rows)[rounds:]:
+            full[y0:y0 + c] = parts[r][at * nx * 3:(at + c) * nx * 3].view(c, nx, 3)
             at += c
     return full
 
@@ -109,7 +127,14 @@ class BandRenderer:
         else:
             self.row_begin, self.row_count = partition_rows(ny, world_size, rank)
             self.state = api.SetCurandState(nx, ny, seed, self.row_begin, self.row_count)
-        self.band = torch.zeros(self.row_count * nx * 3, dtype=torch.float32, device=device)
+        # the piece is rendered straight into the padded send buffer of the gather
+        if self.mode == "strips":
+            max_rows = max(sum(c for _, c in partition_strips(ny, world_size, r)) for r in range(world_size))
+        else:
+            max_rows = partition_rows(ny, world_size, 0)[1]
+        like = torch.zeros(1, dtype=torch.float32, device=device)
+        self.bufs = _GatherBuffers(max_rows * nx * 3, rank, world_size, like)
+        self.band = self.bufs.send[: self.row_count * nx * 3]
 
     def render(self, samples, frame_index=0, stream=None):
         """Enqueue this rank's rows (no synchronisation)."""
@@ -126,5 +151,5 @@ class BandRenderer:
 
     def gather(self, group=None):
         if self.mode == "strips":
-            return gather_strips(self.band, self.nx, self.ny, self.rank, self.world_size, STRIP_ROWS, group)
-        return gather_framebuffer(self.band, self.nx, self.ny, self.rank, self.world_size, group)
+            return gather_strips(self.band, self.nx, self.ny, self.rank, self.world_size, STRIP_ROWS, group, self.bufs)
+        return gather_framebuffer(self.band, self.nx, self.ny, self.rank, self.world_size, group, self.bufs)

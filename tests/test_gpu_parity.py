@@ -351,6 +351,31 @@ def test_binning_is_conservative_on_meshes(gpu):
         assert n_pass > 0 and n_missing == 0 and n_cull == 0, (nx, ny, n_pass, n_missing, n_cull)
 
 
+def test_tiled_equals_brute_force_with_shuffled_triangle_order(gpu, crt_built):
+    """The binning walks 64 consecutive triangles per wavefront: a shuffled mesh makes every
+    wavefront's candidates incoherent (all regions entered, lane = tile classification, unordered
+    lists with ties between coincident edges) — same pixels and RNG states as the brute force."""
+    sc = scenes.displaced_sphere(90, 120)
+    perm = np.random.RandomState(5).permutation(len(sc["idx"]))
+    sc["idx"] = sc["idx"][perm]
+    if sc.get("normals") is not None and len(sc["normals"]) == len(perm):
+        sc["normals"] = sc["normals"][perm]
+    nx, ny, spp = 640, 360, 3
+    scene, cam = make(sc, nx, ny)
+    outs = []
+    for v in (1, 2):
+        prev = crt_built.crt_set_kernel_variant(v)
+        try:
+            (o,), st = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+        finally:
+            crt_built.crt_set_kernel_variant(prev)
+        outs.append((o, st))
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    n_pass, n_missing, n_cull, _ = api.audit_tiles(scene, cam, nx, ny, 2)
+    assert n_pass > 0 and n_missing == 0 and n_cull == 0
+
+
 def test_tiled_equals_brute_force_on_c3_frame(gpu, crt_built):
     """Whole 1920x1080 frame, 100 k triangles, 2 spp: tiled == brute force, bit for bit."""
     sc = scenes.bunny100k()
