@@ -1268,9 +1268,11 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 
 // Classification prepass: per triangle, the exact (fp64) affine coefficients of the four
 // forms over d0(u,v) = (llc - o) + u*H + v*V, rounded to fp32, and the magnitudes M.
-__global__ void __launch_bounds__(256)
+constexpr int kClsThreads = 64;
+__global__ void __launch_bounds__(kClsThreads)
 cls_prepass_kernel(const float* __restrict__ rec, int n, int n_pad, RenderParams p,
                    float4* __restrict__ cls) {
+    __shared__ double poly[2][2][10][kClsThreads];   // clip polygons: [ping-pong][x|y][vertex][lane], 20 KB
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const CameraPOD& cam = p.cam;
@@ -1331,36 +1333,52 @@ cls_prepass_kernel(const float* __restrict__ rec, int n, int n_pad, RenderParams
     if (!finite_all) {
         bu_lo = -pad_u; bu_hi = 1.0 + pad_u; bv_lo = -pad_v; bv_hi = 1.0 + pad_v;
     } else {
-        for (int side = 0; side < 2; ++side) {
-            double px[16], py[16], ox[16], oy[16];
-            int np = 4;
-            px[0] = -pad_u;      py[0] = -pad_v;
-            px[1] = 1.0 + pad_u; py[1] = -pad_v;
-            px[2] = 1.0 + pad_u; py[2] = 1.0 + pad_v;
-            px[3] = -pad_u;      py[3] = 1.0 + pad_v;
+        // corner values decide most triangles at once: a half-plane that excludes all four corners of
+        // the (convex) screen rectangle excludes it entirely
+        auto corners_below = [&](double sgn, int k) {   // sgn * F_k + S < 0 at every corner
+            const double S = (double)p.K_slack * (double)M[k] * 1.01;
+            const double c0 = sgn * FA[k] + S, cb = sgn * FB[k], cc = sgn * FC[k];
+            const double u0 = -pad_u, u1 = 1.0 + pad_u, v0 = -pad_v, v1 = 1.0 + pad_v;
+            return (c0 + u0 * cb + v0 * cc < 0.0) && (c0 + u1 * cb + v0 * cc < 0.0) &&
+                   (c0 + u0 * cb + v1 * cc < 0.0) && (c0 + u1 * cb + v1 * cc < 0.0);
+        };
+        const bool culled = corners_below(1.0, 0);                     // dn < -S everywhere: back-facing on the whole screen
+        for (int side = 0; side < 2 && !culled; ++side) {
+            if (corners_below(side == 0 ? 1.0 : -1.0, 1)) continue;   // a has the other sign everywhere: this side is empty
+            // polygon vertices live in LDS (vertex-major, lane-minor: conflict-free); in private arrays
+            // the dynamic indexing would put them in scratch memory, ten times the latency
+            int cur = 0, np = 4;
+#define PX(b, j) poly[b][0][j][threadIdx.x]
+#define PY(b, j) poly[b][1][j][threadIdx.x]
+            PX(0, 0) = -pad_u;      PY(0, 0) = -pad_v;
+            PX(0, 1) = 1.0 + pad_u; PY(0, 1) = -pad_v;
+            PX(0, 2) = 1.0 + pad_u; PY(0, 2) = 1.0 + pad_v;
+            PX(0, 3) = -pad_u;      PY(0, 3) = 1.0 + pad_v;
             for (int k = 0; k < 5 && np > 0; ++k) {
                 const double sgn = (k == 0 || side == 0) ? 1.0 : -1.0;       // dn keeps its sign on both sides
                 const double S = (double)p.K_slack * (double)M[k] * 1.01;
                 const double ca = sgn * FA[k] + S, cb = sgn * FB[k], cc = sgn * FC[k];   // keep ca + u cb + v cc >= 0
                 int m = 0;
-                double xp = px[np - 1], yp = py[np - 1], fp = ca + xp * cb + yp * cc;
+                double xp = PX(cur, np - 1), yp = PY(cur, np - 1), fp = ca + xp * cb + yp * cc;
                 for (int j = 0; j < np; ++j) {
-                    const double xc = px[j], yc = py[j], fc = ca + xc * cb + yc * cc;
+                    const double xc = PX(cur, j), yc = PY(cur, j), fc = ca + xc * cb + yc * cc;
                     const bool in_c = fc >= 0.0, in_p = fp >= 0.0;
                     if (in_c != in_p) {
                         const double t = fp / (fp - fc);
-                        ox[m] = xp + t * (xc - xp); oy[m] = yp + t * (yc - yp); ++m;
+                        PX(cur ^ 1, m) = xp + t * (xc - xp); PY(cur ^ 1, m) = yp + t * (yc - yp); ++m;
                     }
-                    if (in_c) { ox[m] = xc; oy[m] = yc; ++m; }
+                    if (in_c) { PX(cur ^ 1, m) = xc; PY(cur ^ 1, m) = yc; ++m; }
                     xp = xc; yp = yc; fp = fc;
                 }
                 np = m;
-                for (int j = 0; j < np; ++j) { px[j] = ox[j]; py[j] = oy[j]; }
+                cur ^= 1;
             }
             for (int j = 0; j < np; ++j) {
-                bu_lo = fmin(bu_lo, px[j]); bu_hi = fmax(bu_hi, px[j]);
-                bv_lo = fmin(bv_lo, py[j]); bv_hi = fmax(bv_hi, py[j]);
+                bu_lo = fmin(bu_lo, PX(cur, j)); bu_hi = fmax(bu_hi, PX(cur, j));
+                bv_lo = fmin(bv_lo, PY(cur, j)); bv_hi = fmax(bv_hi, PY(cur, j));
             }
+#undef PX
+#undef PY
         }
     }
     const bool empty = bu_lo > bu_hi;
@@ -1372,7 +1390,7 @@ cls_prepass_kernel(const float* __restrict__ rec, int n, int n_pad, RenderParams
 hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const RenderParams& p,
                               float4* d_cls, hipStream_t stream) {
     if (n_tris <= 0) return hipSuccess;
-    dim3 block(256), grid((unsigned)((n_tris + 255) / 256));
+    dim3 block(kClsThreads), grid((unsigned)((n_tris + kClsThreads - 1) / kClsThreads));
     hipLaunchKernelGGL(cls_prepass_kernel, grid, block, 0, stream, d_rec, n_tris, n_pad, p, d_cls);
     return hipGetLastError();
 }
