@@ -677,6 +677,31 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
                               !(bb.z > v_last + hv_t) && !(bb.y < u_first - hu_t) && !(bb.x > u_last + hu_t);
         if (__builtin_amdgcn_ballot_w64(in_slice) == 0ull) return;
     }
+    // Region range of the wavefront's union box (a superset is enough: every region is still
+    // tested per lane): with a coherent triangle order it is a handful of the screen's regions.
+    int rx_lo = rx_begin, rx_hi = rx_end, ry_lo = ry_begin, ry_hi = ry_end;
+    {
+        const bool odd = have && !(bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w);   // NaN box: keep everything
+        if (__builtin_amdgcn_ballot_w64(odd) == 0ull) {
+            float u0 = have ? bb.x : 1.0e30f, u1 = have ? bb.y : -1.0e30f, v0 = have ? bb.z : 1.0e30f, v1 = have ? bb.w : -1.0e30f;
+#pragma unroll
+            for (int ofs = 32; ofs > 0; ofs >>= 1) {
+                u0 = fminf(u0, __shfl_xor(u0, ofs, 64)); u1 = fmaxf(u1, __shfl_xor(u1, ofs, 64));
+                v0 = fminf(v0, __shfl_xor(v0, ofs, 64)); v1 = fmaxf(v1, __shfl_xor(v1, ofs, 64));
+            }
+            const float cap = 1.0e6f;   // keeps the conversions to int in range; one region of margin each way
+            const float fx0 = fminf(fmaxf((u0 - hu_r) * (float)p.nx * (1.0f / kRegionW), -cap), cap);
+            const float fx1 = fminf(fmaxf((u1 + hu_r) * (float)p.nx * (1.0f / kRegionW), -cap), cap);
+            rx_lo = max(rx_begin, (int)floorf(fx0) - 1);
+            rx_hi = min(rx_end, (int)floorf(fx1) + 2);
+            if (p.strip_step == 1) {   // contiguous rows: local row = global row - row_begin
+                const float fy0 = fminf(fmaxf(((v0 - hv_r) * (float)p.ny - (float)p.row_begin) * (1.0f / kRegionH), -cap), cap);
+                const float fy1 = fminf(fmaxf(((v1 + hv_r) * (float)p.ny - (float)p.row_begin) * (1.0f / kRegionH), -cap), cap);
+                ry_lo = max(ry_begin, (int)floorf(fy0) - 1);
+                ry_hi = min(ry_end, (int)floorf(fy1) + 2);
+            }
+        }
+    }
     const float ru_lo = bb.x - hu_r, ru_hi = bb.y + hu_r;
     const float tu_lo = bb.x - hu_t, tu_hi = bb.y + hu_t, tv_lo = bb.z - hv_t, tv_hi = bb.w + hv_t;
     const FormSet f = load_forms(cls, n_pad, have ? tri : 0);   // coalesced: 1 KiB per plane and wavefront
@@ -687,7 +712,7 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
         qr[k] = __builtin_fmaf(p.K_slack, f.M[k], __builtin_fmaf(hv_r, fabsf(f.C[k]), hu_r * fabsf(f.B[k])) * 1.0001f);
     }
     float c[5];
-    for (int ry = ry_begin; ry < ry_end; ++ry) {
+    for (int ry = ry_lo; ry < ry_hi; ++ry) {
         // 32 local rows: inside one strip, so the region's global rows are contiguous
         const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ry * kRegionH);
         const float vcr = (float)(gy + kRegionH / 2) * rny;
@@ -696,7 +721,7 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
         float row1[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) row1[k] = __builtin_fmaf(vcr, f.C[k], f.A[k]);
-        for (int rx = rx_begin; rx < rx_end; ++rx) {
+        for (int rx = rx_lo; rx < rx_hi; ++rx) {
             const float ucr = (float)(rx * kRegionW + kRegionW / 2) * rnx;
             const bool s1_box = in_row && !(ucr < ru_lo) && !(ucr > ru_hi);
             if (__builtin_amdgcn_ballot_w64(s1_box) == 0ull) continue;
@@ -1047,13 +1072,16 @@ __device__ __forceinline__ unsigned long long hit_key(float t, int idx) {
     return ((unsigned long long)ordered << 32) | (unsigned long long)(unsigned)idx;
 }
 
-// ---- kernel 2 of the tiled variant: shading.  Persistent 1024-thread blocks pull tiles
-// from the work queues.  Heavy tiles (classes 0-2, heaviest first) are traced by all 16
-// waves of a block together: every wave traces the same 64 rays against its own slice of
-// the tile's list (slices ascend in index), the partial (t, index) minima are merged
-// through LDS in slice order with the reference's strict `<`, and every wave replays the
-// same shading / RNG so the streams stay in step.  Light tiles (class 3) are then pulled
-// one per wave.
+// ---- shading kernel of the tiled variant.  Persistent blocks of WAVES wavefronts (exactly as
+// many blocks as are resident) take tiles from the work queues.  Heavy tiles (heaviest first;
+// block b starts with item b) are traced by all waves of a block together: wave 0 owns the
+// pixels' RNG streams, generates the 64 rays of a sample and publishes them in LDS; every wave
+// traces them against its own slice of the tile's list; the partial results meet in LDS as
+// 64-bit (ordered t, index) keys (atomicMin = the reference's accept rule); wave 0 shades.
+// Light tiles are then pulled one per wave from 64 interleaved chunks of the light queue
+// (one cursor per cache line).  VREC: the slice / list is staged in LDS and every lane walks
+// only the entries that can be hit from ITS pixel (stage_candidates / trace_candidates);
+// !VREC (variant 4, A/B): wave-uniform walks with scalar-operand records.
 template <bool VREC, int OCC, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
