@@ -502,14 +502,15 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
         V3 sky = sky_from_unit(d1);                                    // backgroundSky(r.direction())
         if (hit_idx >= 0) {                                            // LambertShade, render.h:75-83
             // Lambertian::scatter -> random_in_unit_sphere: only the draws matter (material.h:11-19,66)
+            const float* sn = shade_n + (size_t)hit_idx * 3;           // normal after both rotate() calls
+            const float snx = sn[0], sny = sn[1], snz = sn[2];         // requested before the draws: the latency overlaps them
             float sxr, syr, szr;
             do {
                 sxr = 2.0f * xw_uniform(rs) - 1.0f;
                 syr = 2.0f * xw_uniform(rs) - 1.0f;
                 szr = 2.0f * xw_uniform(rs) - 1.0f;
             } while (sxr * sxr + syr * syr + szr * szr >= 1.0f);
-            const float* sn = shade_n + (size_t)hit_idx * 3;           // normal after both rotate() calls
-            float t = d0.x * sn[0] + d0.y * sn[1] + d0.z * sn[2];      // dot(r.direction(), rec.normal)
+            float t = d0.x * snx + d0.y * sny + d0.z * snz;            // dot(r.direction(), rec.normal)
             if (t < 0.0f) t = 0.0f;
             // attenuation * t * backgroundSky(...) * 0.2 + emitted
             colx += 0.2f * ((t * p.albedo[0]) * sky.x) + 0.0f;

@@ -343,6 +343,46 @@ def test_binning_is_conservative_for_every_passing_pair(gpu, kind):
         assert n_missing == 0 and n_cull == 0, (kind, seed, n_pass, n_missing, n_cull, offender >> 32, offender & 0xffffffff)
 
 
+@pytest.mark.parametrize("cam", [
+    dict(lookfrom=(3.0e4, -2.0e4, 5.0e4), lookat=(3.0e4 + 0.2, -2.0e4 + 0.1, 5.0e4 - 1.0), vfov=40.0, focus=0.05),   # |llc| / |d0| ~ 1e6
+    dict(lookfrom=(0.0, 0.0, 4.0), lookat=(0.3, -0.2, 0.0), vfov=150.0, focus=10.0),                                 # very wide
+    dict(lookfrom=(7.0, 9.0, 4.0), lookat=(6.0, 2.0, 1.0), vfov=3.0, focus=1000.0),                                  # very narrow, long focus
+    dict(lookfrom=(0.0, 50.0, 0.001), lookat=(0.0, 0.0, 0.0), vfov=60.0, focus=2.0),                                 # looking almost along vup
+])
+def test_position_slack_on_extreme_cameras(gpu, crt_built, cam):
+    """The binning prices the float evaluation of the ray direction as a shift of the screen
+    position (camera_slacks): cameras with heavy cancellation, extreme fields of view and a view
+    direction next to vup must still be conservative (audit) and equal to the brute force."""
+    rng = np.random.RandomState(21)
+    lf, la = np.array(cam["lookfrom"], np.float64), np.array(cam["lookat"], np.float64)
+    w = (la - lf) / np.linalg.norm(la - lf)
+    n = 300
+    depth = rng.uniform(2.0, 40.0, size=(n, 1))
+    centre = lf + w * depth + rng.normal(size=(n, 3)) * depth * np.tan(np.radians(min(cam["vfov"], 120.0)) / 2) * 0.8
+    size = depth * rng.uniform(0.002, 0.3, size=(n, 1))
+    pts = (centre[:, None, :] + rng.normal(size=(n, 3, 3)) * size[:, None, :]).reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.float32).reshape(n, 3)
+    sc = dict(points=pts, idx=idx, normals=None, index_base=0,
+              camera=dict(lookfrom=cam["lookfrom"], lookat=cam["lookat"], vfov=cam["vfov"], aperture=0.0, focus=cam["focus"]))
+    nx, ny, spp = 160, 96, 4
+    scene, camera = make(sc, nx, ny)
+    outs = []
+    for v in (1, 2):
+        prev = crt_built.crt_set_kernel_variant(v)
+        try:
+            (o,), st = hip_render_with_states(gpu, scene, camera, nx, ny, spp)
+        finally:
+            crt_built.crt_set_kernel_variant(prev)
+        outs.append((o, st))
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0]))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    try:
+        n_pass, n_missing, n_cull, _ = api.audit_tiles(scene, camera, nx, ny, 4)
+    except api.CrtError:
+        return                      # ill-conditioned camera: the library renders it with the brute-force kernel
+    assert n_missing == 0 and n_cull == 0, (n_pass, n_missing, n_cull)
+
+
 def test_binning_is_conservative_on_meshes(gpu):
     for sc, nx, ny, spp in [(scenes.cornell32(), 200, 150, 8), (scenes.displaced_sphere(60, 80), 320, 180, 4),
                             (scenes.quad(), 64, 64, 8)]:
