@@ -54,6 +54,7 @@ PROTOTYPES = {
     "crt_scene_from_mesh": (C.c_void_p, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp]),
     "crt_scene_from_obj": (C.c_void_p, [C.c_char_p, C.c_float, _fp]),
     "crt_scene_triangle_count": (C.c_int, [C.c_void_p]),
+    "crt_scene_update_pose": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "crt_scene_free": (None, [C.c_void_p]),
     "crt_parse_obj": (C.c_int, [C.c_char_p, _fp, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "crt_rng_create": (C.c_void_p, [C.c_int64, C.c_int64, C.c_uint64]),

@@ -83,6 +83,13 @@ class Scene:
     def n_triangles(self):
         return _lib.lib().crt_scene_triangle_count(self.handle)
 
+    def update_pose(self, new_points, stream=None):
+        """updateFBXObj's device half (update_pose, createScene.h:99-110): new vertex positions
+        through the same indices; stored normals are kept."""
+        pts = np.ascontiguousarray(new_points, dtype=np.float32).reshape(-1, 3)
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        check(_lib.lib().crt_scene_update_pose(self.handle, _fp(pts), len(pts), st))
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().crt_scene_free(self.handle)
@@ -244,16 +251,20 @@ def WritePng(nx, ny, frameIndex, colorBuffer, folder="images/moveTest"):
 
 
 def renderListAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world, camera,
-                        curand_state, write_png=True, folder="images/moveTest"):
-    """renderListAnimation, core/render.h:159-189 for a static mesh: per frame launch the
-    render kernel on the whole image, synchronise, copy back, WritePng.  The RNG states
-    persist across frames as in the reference.  Returns the list of frames."""
+                        curand_state, write_png=True, folder="images/moveTest", poses=None):
+    """renderListAnimation, core/render.h:159-189: per frame [update the mesh pose,] launch the
+    render kernel on the whole image, synchronise, copy back, WritePng.  The RNG states persist
+    across frames as in the reference.  `poses` (optional) maps a frame index to that frame's
+    point positions — the output of the reference's calcPose, which needs the FBX SDK; the
+    device half of updateFBXObj is Scene.update_pose.  Returns the list of frames."""
     import torch
     if not torch.cuda.is_available():
         raise CrtError(_lib.CRT_ERR_NO_DEVICE, "renderListAnimation: no HIP device (no CPU fallback)")
     d_colorBuffer = torch.zeros(ny * nx * 3, dtype=torch.float32, device="cuda")
     frames = []
     for frameIndex in range(beginFrame, endFrame + 1):
+        if poses is not None:                                   # updateFBXObj(frameIndex, obj, ...), render.h:177
+            world.update_pose(poses[frameIndex], stream=torch.cuda.current_stream())
         render_rows(world, camera, curand_state, nx, ny, samples, 0, ny, d_colorBuffer,
                     max_depth=max_depth, frame_index=frameIndex,
                     stream=torch.cuda.current_stream())

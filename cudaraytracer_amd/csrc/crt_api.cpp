@@ -262,6 +262,9 @@ struct crt_scene {
     float4* d_cls = nullptr;      // 4 planes x n_pad classification records (tiled variant)
     int n_pad = 0;
     bool tiled_safe = false;      // all coordinates finite and |c| <= 2^38
+    int n_points = 0;             // update_pose: size of the point array the indices refer to
+    int* d_idx = nullptr;         // n x 3 vertex indices, 0-based (as given: idx[0], idx[1], idx[2])
+    float* d_points = nullptr;    // n_points x 3 staging of the current pose
 };
 
 struct crt_rng {
@@ -328,6 +331,7 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
     bool finite = true;
     std::vector<float> base((size_t)std::max(n_tris, 1) * crt::kBaseFloats);
     std::vector<float> shade((size_t)std::max(n_tris, 1) * 3);
+    std::vector<int> idx0((size_t)std::max(n_tris, 1) * 3);
     for (int i = 0; i < n_tris; ++i) {
         int id[3];
         for (int k = 0; k < 3; ++k) {
@@ -338,6 +342,7 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
                 return nullptr;
             }
         }
+        for (int k = 0; k < 3; ++k) idx0[3 * (size_t)i + k] = id[k];
         float* b = &base[(size_t)i * crt::kBaseFloats];
         for (int k = 0; k < 3; ++k)   // v = {points[idx[2]], points[idx[1]], points[idx[0]]}
             memcpy(b + 3 * k, points + 3 * (size_t)id[2 - k], 3 * sizeof(float));
@@ -371,6 +376,9 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
     if (e == hipSuccess) e = hipMalloc(&s->d_shade_n, nalloc * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&s->d_rec, nalloc * crt::kRecFloats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&s->d_cls, (size_t)crt::kClsPlanes * s->n_pad * sizeof(float4));
+    s->n_points = n_points;
+    if (e == hipSuccess) e = hipMalloc(&s->d_idx, nalloc * 3 * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(s->d_idx, idx0.data(), nalloc * 3 * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_base, base.data(), nalloc * crt::kBaseFloats * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_shade_n, shade.data(), nalloc * 3 * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -437,6 +445,27 @@ crt_scene* crt_scene_from_obj(const char* path, float scale, const float albedo[
     return crt_scene_from_mesh(pts.data(), np, idx.data(), nt, nullptr, 1, albedo);
 }
 
+int crt_scene_update_pose(crt_scene* s, const float* new_points, int n_points, void* stream_) {
+    // updateFBXObj's device half (createScene.h:99-110,126-140): H2D copy of the new point
+    // positions, then every triangle re-reads its vertices; normals are kept.
+    if (!s || !new_points) return fail(CRT_ERR_INVALID, "crt_scene_update_pose: null argument");
+    if (n_points != s->n_points)
+        return fail(CRT_ERR_INVALID, "crt_scene_update_pose: %d points, the scene was built from %d", n_points, s->n_points);
+    if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_scene_update_pose: no HIP device");
+    hipStream_t stream = (hipStream_t)stream_;
+    bool finite = true;
+    float max_abs = 0.0f;
+    for (size_t k = 0; k < (size_t)n_points * 3; ++k) {
+        finite = finite && std::isfinite(new_points[k]);
+        max_abs = std::max(max_abs, fabsf(new_points[k]));
+    }
+    if (!s->d_points) HIP_TRY(hipMalloc(&s->d_points, (size_t)n_points * 3 * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(s->d_points, new_points, (size_t)n_points * 3 * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_TRY(crt::launch_update_pose(s->d_points, s->d_idx, s->n_tris, s->d_base, stream));
+    s->tiled_safe = finite && max_abs <= 274877906944.0f;   // 2^38, as at creation (here over all points)
+    return CRT_OK;
+}
+
 int crt_scene_triangle_count(const crt_scene* s) { return s ? s->n_tris : CRT_ERR_INVALID; }
 
 void crt_scene_free(crt_scene* s) {
@@ -445,6 +474,8 @@ void crt_scene_free(crt_scene* s) {
     if (s->d_shade_n) (void)hipFree(s->d_shade_n);
     if (s->d_rec) (void)hipFree(s->d_rec);
     if (s->d_cls) (void)hipFree(s->d_cls);
+    if (s->d_idx) (void)hipFree(s->d_idx);
+    if (s->d_points) (void)hipFree(s->d_points);
     delete s;
 }
 

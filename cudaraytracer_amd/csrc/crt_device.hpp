@@ -76,6 +76,7 @@ hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long c
                            int strip_step, uint64_t seed, const uint32_t* d_jump, hipStream_t stream);
 hipError_t launch_tri_prepass(const float* d_base, int n_tris, const float origin[3],
                               float* d_rec, hipStream_t stream);
+hipError_t launch_update_pose(const float* d_points, const int* d_idx, int n_tris, float* d_base, hipStream_t stream);
 hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const RenderParams& p,
                               float4* d_cls, hipStream_t stream);
 // variant 0: brute force (every ray x every triangle); 1: tiled (conservative region/tile

@@ -155,6 +155,30 @@ tri_prepass_kernel(const float* __restrict__ base, int n, float ox, float oy, fl
     o[3] = make_float4(qx, qy, qz, tq);
 }
 
+// update_pose (createScene.h:99-110; a single device thread in the reference): lane = triangle,
+// the three vertices are re-read from the new point positions through the triangle's (already
+// 0-based, validated) indices in the pack's reversed winding; the stored normal stays.
+__global__ void __launch_bounds__(256)
+update_pose_kernel(const float* __restrict__ points, const int* __restrict__ idx, int n, float* __restrict__ base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* b = base + (size_t)i * kBaseFloats;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // v = {points[idx[2]], points[idx[1]], points[idx[0]]}
+        const float* q = points + 3 * (size_t)idx[3 * (size_t)i + (2 - k)];
+        b[3 * k + 0] = q[0];
+        b[3 * k + 1] = q[1];
+        b[3 * k + 2] = q[2];
+    }
+}
+
+hipError_t launch_update_pose(const float* d_points, const int* d_idx, int n_tris, float* d_base, hipStream_t stream) {
+    if (n_tris <= 0) return hipSuccess;
+    hipLaunchKernelGGL(update_pose_kernel, dim3((unsigned)((n_tris + 255) / 256)), dim3(256), 0, stream, d_points, d_idx,
+                       n_tris, d_base);
+    return hipGetLastError();
+}
+
 hipError_t launch_tri_prepass(const float* d_base, int n_tris, const float origin[3],
                               float* d_rec, hipStream_t stream) {
     if (n_tris <= 0) return hipSuccess;

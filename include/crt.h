@@ -86,6 +86,13 @@ crt_scene *crt_scene_from_mesh(const float *points, int n_points, const float *i
                                int n_tris, const float *face_normals, int index_base,
                                const float albedo[3]);
 
+/* Replaces update_pose / updateFBXObj's device half (createScene.h:99-110,126-140): the vertices of
+ * every triangle are re-read from `new_points` (n_points x 3 floats, host; n_points must equal the
+ * count the scene was built from) through the scene's index triplets in the same reversed winding;
+ * stored normals are kept (Triangle::SetVertices, shapes/triangle.h:40-45).  Enqueued on `stream`
+ * (hipStream_t, NULL = default); the next crt_render_rows on that stream sees the new pose. */
+int crt_scene_update_pose(crt_scene *scene, const float *new_points, int n_points, void *stream);
+
 /* replaces: parseObjByName (Loader/obj_loader.h:20-111) + computeMean/centering
  * (:120-133) + the historic `points[i] *= 100.0` scale (:164) + the scene pack above with
  * index_base 1 and computed normals.  Only `v x y z` and `f a b c` records are read, as

@@ -528,6 +528,25 @@ o_world *o_world_from_mesh(const float *points, int n_points, const float *idx3f
     return w;
 }
 
+/* update_pose, createScene.h:99-110 (the device half of updateFBXObj, :126-140): every
+ * triangle's vertices are re-read from the new point positions through the same float index
+ * triplets and the same reversed winding; the stored normal is NOT touched (Triangle::SetVertices,
+ * shapes/triangle.h:40-45). */
+int o_world_update_pose(o_world *w, const float *new_points, int n_points, const float *idx3f, int index_base) {
+    for (int i = 0; i < w->list_size; i++) {
+        int id[3];
+        for (int k = 0; k < 3; k++) {
+            id[k] = (int)idx3f[3 * i + k] - index_base;
+            if (id[k] < 0 || id[k] >= n_points) return -1;
+        }
+        for (int k = 0; k < 3; k++) {
+            int p = id[2 - k];
+            w->list[i].vertices[k] = v3(new_points[3 * p], new_points[3 * p + 1], new_points[3 * p + 2]);
+        }
+    }
+    return 0;
+}
+
 void o_world_free(o_world *w) {
     if (!w) return;
     free(w->list);

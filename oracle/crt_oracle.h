@@ -86,6 +86,8 @@ void o_camera_init(o_camera *cam, const float lookfrom[3], const float lookat[3]
 o_world *o_world_from_mesh(const float *points, int n_points, const float *idx3f,
                            int n_tris, const float *normals, int index_base,
                            const float albedo[3]);
+/* createScene.h:99-110 update_pose: new vertex positions, normals kept.  -1: index out of range. */
+int o_world_update_pose(o_world *w, const float *new_points, int n_points, const float *idx3f, int index_base);
 void o_world_free(o_world *w);
 
 /* ---- OBJ: Loader/obj_loader.h:20-133. Two-call protocol: pass NULL buffers to count. */

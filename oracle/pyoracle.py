@@ -53,6 +53,8 @@ def lib():
         L.o_camera_init.argtypes = [C.POINTER(Camera), fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]
         L.o_world_from_mesh.argtypes = [fp, C.c_int, fp, C.c_int, fp, C.c_int, fp]
         L.o_world_from_mesh.restype = C.c_void_p
+        L.o_world_update_pose.argtypes = [C.c_void_p, fp, C.c_int, fp, C.c_int]
+        L.o_world_update_pose.restype = C.c_int
         L.o_world_free.argtypes = [C.c_void_p]
         L.o_parse_obj.argtypes = [C.c_char_p, fp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.o_render_window.argtypes = [fp, C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_int] * 9
@@ -113,6 +115,14 @@ class World:
         if not self.handle:
             raise ValueError("o_world_from_mesh: vertex index out of range")
         self.n_tris = len(self.idx3f)
+        self.index_base = index_base
+
+    def update_pose(self, new_points):
+        """update_pose (createScene.h:99-110): new vertex positions, stored normals kept."""
+        pts = np.ascontiguousarray(new_points, dtype=np.float32).reshape(-1, 3)
+        if lib().o_world_update_pose(self.handle, _fp(pts), len(pts), _fp(self.idx3f), self.index_base) != 0:
+            raise ValueError("o_world_update_pose: vertex index out of range")
+        self.points = pts
 
     def __del__(self):
         if getattr(self, "handle", None):

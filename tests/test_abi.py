@@ -117,6 +117,8 @@ def test_compute_entry_points_fail_loudly_without_device(crt_built):
     assert rc == _lib.CRT_ERR_NO_DEVICE
     with pytest.raises(_lib.CrtError):
         api.renderListAnimation(2, 2, 1, 8, 0, 0, None, cam, None)
+    pts = np.zeros(9, dtype=np.float32)
+    assert L.crt_scene_update_pose(None, pts.ctypes.data_as(C.POINTER(C.c_float)), 3, None) == _lib.CRT_ERR_INVALID
 
 
 def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):

@@ -195,6 +195,39 @@ def test_frames_continue_the_rng_streams(gpu, oracle, variant):
     assert np.array_equal(a, b)
 
 
+def test_pose_updates_between_frames_match_oracle(gpu, oracle, variant):
+    """The animation loop (core/render.h:174-186): updateFBXObj's update_pose rewrites every
+    triangle's vertices from the frame's point positions (normals kept, createScene.h:99-110),
+    then the frame is rendered with the RNG states of the previous one."""
+    sc = scenes.displaced_sphere(10, 12)
+    rng = np.random.RandomState(3)
+    nx, ny, spp = 48, 32, 3
+    pts0 = np.asarray(sc["points"], np.float32).reshape(-1, 3)
+    idx = np.asarray(sc["idx"], np.float32).reshape(-1, 3)
+    normals = rng.normal(size=(len(idx), 3)).astype(np.float32)          # create_FBXMesh always passes face normals
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True).astype(np.float32)
+    sc = dict(sc, normals=normals)
+    poses = [pts0,
+             (pts0 * np.float32(1.1) + np.array([5.0, -3.0, 2.0], np.float32)).astype(np.float32),
+             (pts0 + rng.normal(scale=4.0, size=pts0.shape)).astype(np.float32)]
+    scene, cam = make(sc, nx, ny)
+    w, ocam = oracle_pair(oracle, sc, nx, ny)
+    st = api.SetCurandState(nx, ny, 0)
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    ost = None
+    for f, pose in enumerate(poses):
+        scene.update_pose(pose, stream=gpu.cuda.current_stream())
+        api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, frame_index=f, stream=gpu.cuda.current_stream())
+        gpu.cuda.synchronize()
+        w.update_pose(pose)
+        ref, ost = oracle.render(w, ocam, nx, ny, spp, states=ost)
+        got = bits(d.cpu().numpy().reshape(ny, nx, 3)).reshape(-1, 3)
+        skip = 0 if f == 0 else 1                                          # pixel 0 of later frames: state[0] race
+        assert np.array_equal(got[skip:], bits(ref).reshape(-1, 3)[skip:]), f
+    with pytest.raises(api.CrtError):
+        scene.update_pose(pts0[:-1])                                       # wrong point count
+
+
 def test_row_bands_equal_full_image(gpu, variant):
     sc = scenes.displaced_sphere(10, 12)
     nx, ny, spp = 100, 75, 2

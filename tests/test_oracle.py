@@ -256,3 +256,18 @@ def test_obj_parse_and_centering(oracle, tmp_path):
         mean = (mean + p).astype(np.float32)
     mean = (mean / np.float32(len(sc["points"]))).astype(np.float32)
     assert np.array_equal(pts, (sc["points"] - mean).astype(np.float32))
+
+
+def test_update_pose_moves_vertices_and_keeps_normals(oracle):
+    """update_pose (createScene.h:99-110): same hit test on the moved triangle, stored normal unchanged."""
+    pts = np.array([[-1, -1, -5], [1, -1, -5], [1, 1, -5], [-1, 1, -5]], np.float32)
+    idx = np.array([[0, 1, 2], [0, 2, 3]], np.float32)
+    nrm = np.array([[0, 0, -1], [0, 0, -1]], np.float32)
+    w = oracle.World(pts, idx, nrm, 0)
+    hit, t0, i0, n0 = w.hit((0, 0, 0), (0, 0, -1))
+    assert hit and t0 == np.float32(5.0)
+    w.update_pose(pts + np.array([0, 0, -5], np.float32))
+    hit, t1, i1, n1 = w.hit((0, 0, 0), (0, 0, -1))
+    assert hit and t1 == np.float32(10.0) and i1 == i0 and np.array_equal(n0, n1)
+    w.update_pose(pts + np.array([10, 0, 0], np.float32))
+    assert not w.hit((0, 0, 0), (0, 0, -1))[0]
