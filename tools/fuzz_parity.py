@@ -12,7 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 L = _lib.lib()
 t0 = time.time()
-n_cases = n_audit_pairs = 0
+n_cases = n_audit_pairs = n_strip_cases = 0
 while time.time() - t0 < budget:
     rng = np.random.RandomState(seed)
     n = int(rng.choice([1, 7, 63, 64, 65, 300, 2000, 20000]))
@@ -52,9 +52,23 @@ while time.time() - t0 < budget:
         n_audit_pairs += audit[0]
     except api.CrtError:
         pass
+    if ok and ny >= 64 and rng.rand() < 0.5:   # one rank's round-robin strips of a W-way split == those rows of the full frame
+        from cudaraytracer_amd.dist import partition_strips
+        W = int(rng.choice([2, 3, 8])); r = int(rng.randint(0, W))
+        strips = partition_strips(ny, W, r)
+        if strips:
+            rows = sum(c for _, c in strips)
+            stp = api.CurandState.for_strips(nx, ny, r, 32, W, seed)
+            piece = torch.zeros(rows * nx * 3, device="cuda")
+            api.render_strips(scene, cam, stp, nx, ny, spp, r, 32, W, piece)
+            torch.cuda.synchronize()
+            full = outs[1][0].reshape(ny, nx, 3)
+            want = np.concatenate([full[y0:y0 + c] for y0, c in strips])
+            ok = np.array_equal(piece.cpu().numpy().view(np.uint32).reshape(rows, nx, 3), want)
+            n_strip_cases += 1
     if not ok:
         print("MISMATCH seed %d: n=%d %dx%d spp %d vfov %g focus %g audit %s" % (seed, n, nx, ny, spp, vfov, focus, audit), flush=True)
         sys.exit(1)
     n_cases += 1
     seed += 1
-print("fuzz ok: %d cases (seeds up to %d), %d audited passing pairs, %.0f s" % (n_cases, seed - 1, n_audit_pairs, time.time() - t0))
+print("fuzz ok: %d cases (seeds up to %d), %d of them also as one rank's strips, %d audited passing pairs, %.0f s" % (n_cases, seed - 1, n_strip_cases, n_audit_pairs, time.time() - t0))
