@@ -99,8 +99,8 @@ def cpu_baseline(obj_path, budget_rays=1536):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--variant", type=int, default=0, help=argparse.SUPPRESS)
@@ -159,13 +159,18 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        kernel_ms.append(api.last_kernel_times())          # HIP events on the launch stream
+        step()                                             # enqueue only: no host synchronisation inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
+
+    # per-kernel durations (HIP events on the launch stream; reading them synchronises, so these
+    # frames are outside the timed region)
+    kernel_ms = []
+    for _ in range(min(args.steps, 5)):
+        br.render(args.spp, stream=stream)
+        kernel_ms.append(api.last_kernel_times())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (world > 1 and share) else "cuda")
     if world > 1:
