@@ -605,7 +605,7 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
 //   binning (lane = triangle) -> per-tile survivor lists; shading (lane = pixel) -> the reference
 //   arithmetic (exact_test) on the tile's survivors only.
 constexpr int kHeavyMinSmall = 16, kHeavyMinMedium = 24;   // same for small launches (< 24 / < 96 tiles per CU)
-constexpr int kHeavyMin = 48;  // tiles with more survivors than this are traced by all waves of a block together (measured optimum, 12..64 swept)
+constexpr int kHeavyMin = 32;  // tiles with more survivors than this are traced by all waves of a block together (measured optimum, 12..64 swept)
 constexpr unsigned kNoList = 0xffffffffu;   // tile_desc.y: the pool was full, walk every triangle
 constexpr unsigned kCullSureBit = 0x80000000u;   // pool entry flag: the cull test cannot reject in this tile
 
@@ -1097,6 +1097,63 @@ __device__ __forceinline__ unsigned long long hit_key(float t, int idx) {
     return ((unsigned long long)ordered << 32) | (unsigned long long)(unsigned)idx;
 }
 
+// ---- balanced candidate walk.  The step count of trace_candidates is the LONGEST per-pixel list
+// of the wavefront while the mean is much shorter.  When the (pixel, entry) pairs of the staged
+// entries fit the wave's pair buffer they are laid out once per tile, evenly over the lanes:
+// every sample then takes ceil(pairs / 64) steps, each lane testing the ray of its pair's pixel
+// against its pair's entry; the results meet per pixel as (ordered t, index) keys (atomicMin =
+// the reference's accept rule).  Pair word: pixel | entry << 6 | cull-sure << 12.
+// Returns the number of pairs, or 0xffffffff when they do not fit (nothing written).
+__device__ __forceinline__ unsigned build_pairs(const Cand& cand, int lane, unsigned short* __restrict__ pairs, unsigned cap) {
+    const unsigned pc = (unsigned)(__builtin_popcount(cand.lo) + __builtin_popcount(cand.hi));
+    unsigned incl = pc;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const unsigned v = __shfl_up(incl, ofs, 64);
+        if (lane >= ofs) incl += v;
+    }
+    const unsigned total = __shfl(incl, 63, 64);
+    if (total > cap) return 0xffffffffu;
+    unsigned at = incl - pc;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        unsigned m = half ? cand.hi : cand.lo;
+        const unsigned sm = half ? cand.sure_hi : cand.sure_lo;
+        while (m != 0u) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1u;
+            pairs[at++] = (unsigned short)((unsigned)lane | (unsigned)(half * 32 + j) << 6 | ((sm >> j) & 1u) << 12);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return total;
+}
+
+// One sample: all pairs against the rays ray_of(pixel); minima into keys[pixel].  All 64 lanes active.
+template <class RayOf>
+__device__ __forceinline__ void trace_pairs(StageArea& area, const int* ent, const unsigned short* __restrict__ pairs,
+                                            unsigned n_pairs, int lane, RayOf ray_of, unsigned long long* keys) {
+    for (unsigned base = 0; base < n_pairs; base += 64u) {
+        const unsigned j = base + (unsigned)lane;
+        const bool active = j < n_pairs;
+        const unsigned pr = active ? (unsigned)pairs[j] : 0u;
+        const int pix = (int)(pr & 63u), k = (int)((pr >> 6) & 63u);
+        const V3 dp = ray_of(pix);
+        const int e = ent[k];
+        RecV rc;
+        rc.a = area[0][k];
+        rc.b = area[1][k];
+        rc.c = area[2][k];
+        rc.d = area[3][k];
+        float t_pair = FLT_MAX;
+        int i_pair = -1;
+        exact_test_lane<true>(rc, e & 0x7fffffff, ((pr >> 12) & 1u) != 0u || e < 0, active, dp, t_pair, i_pair);
+        if (i_pair >= 0) atomicMin(&keys[pix], hit_key(t_pair, i_pair));
+    }
+}
+
 // ---- shading kernel of the tiled variant.  Persistent blocks of WAVES wavefronts (exactly as
 // many blocks as are resident) take tiles from the work queues.  Heavy tiles (heaviest first;
 // block b starts with item b) are traced by all waves of a block together: wave 0 owns the
@@ -1111,18 +1168,24 @@ template <bool VREC, int OCC, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
-                   TiledWork w, unsigned long long* __restrict__ stats, int dbg_repeat) {
+                   TiledWork w, unsigned long long* __restrict__ stats, int dbg_repeat_in) {
     __shared__ unsigned long long best_key[64];   // per pixel: min over the waves of (ordered t, index)
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
     __shared__ StageArea lrec[VREC ? WAVES : 1];       // this wave's staged list entries: forms, then exact records (4 KB per wave)
     __shared__ float lqw[VREC ? WAVES : 1][64];        // slack + radius of the fifth form of the staged entries
     __shared__ int lent[VREC ? WAVES : 1][64];         // pool words of the staged entries
+    // balanced candidate walk of light tiles (8-wave blocks only: the LDS of 16-wave blocks is spoken for)
+    constexpr int kPairCap = (VREC && WAVES <= 8) ? 512 : 1;
+    __shared__ unsigned short lpairs[(VREC && WAVES <= 8) ? WAVES : 1][kPairCap];   // (pixel | entry << 6 | cull-sure << 12)
+    __shared__ unsigned long long lkey[(VREC && WAVES <= 8) ? WAVES : 1][64];       // per pixel: min (ordered t, index)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_tris = p.n_tris;
+    const int dbg_pairs = (dbg_repeat_in < 0) ? 0 : 1;   // tuning hook: a negative repeat count switches the balanced walk off
+    const int dbg_repeat = (dbg_repeat_in < 0) ? -dbg_repeat_in : dbg_repeat_in;
     const long long clk0 = stats ? (long long)clock64() : 0;
 
     // ---- heavy tiles: the classes form one list, heaviest first.  Block b starts with item b
@@ -1165,9 +1228,17 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
                                  global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
             }
+            unsigned slice_pairs = 0xffffffffu;   // balanced walk of the staged part of the slice (rays and keys are in LDS anyway)
+            if (VREC && WAVES <= 8 && n_lds > 0 && dbg_pairs != 0) {
+                if (!lane_valid) cand.lo = cand.hi = 0u;
+                slice_pairs = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
+            }
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
-                if (n_lds > 0) trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
+                if (slice_pairs != 0xffffffffu)
+                    trace_pairs(lrec[wave], lent[wave], lpairs[wave], slice_pairs, lane,
+                                [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key);
+                else if (n_lds > 0) trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
                 if (!walk_all) walk_list<true>(rec, lst, k0 + n_lds, k1, lane, d2, closest, hit_idx);
                 else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
               }
@@ -1289,9 +1360,40 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 atomicAdd(&stats[40], (unsigned long long)sm);
             }
         }
+        // Balanced walk: the step count of trace_candidates is the LONGEST per-pixel list of the wave
+        // while the mean is much shorter.  When the tile's (pixel, entry) pairs fit, they are laid out
+        // once per tile, evenly over the lanes: every sample then takes ceil(pairs / 64) steps; a lane
+        // fetches the ray of its pair's pixel with ds_bpermute and the results meet per pixel in LDS
+        // as (ordered t, index) keys (atomicMin = the reference's accept rule).
+        unsigned n_pairs = 0xffffffffu;
+        if (VREC && WAVES <= 8 && cnt > 0 && dbg_pairs != 0) {
+            if (!(x < p.nx && ly < p.row_count)) cand.lo = cand.hi = 0u;   // lanes off the image replay a pixel: no pairs of their own
+            n_pairs = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
+        }
+        const bool pair_mode = n_pairs != 0xffffffffu;
         if (cnt == 0) {   // background only (most tiles of a typical frame)
             if (x < p.nx && ly < p.row_count)
                 render_pixel<true, true>(p, x, ly, shade_n, state, rgb, true, [](V3, float&, int&) {});
+        } else if (pair_mode) {   // all 64 lanes stay active (ds_bpermute reads lanes); off-image lanes replay a valid pixel, unstored
+            render_pixel<true>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, x < p.nx && ly < p.row_count,
+                         [&](V3 d2, float& closest, int& hit_idx) {
+              for (int rep = 0; rep < dbg_repeat; ++rep) {
+                lkey[wave][lane] = ~0ull;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                trace_pairs(lrec[wave], lent[wave], lpairs[wave], n_pairs, lane, [&](int pix) {   // the ray of another lane: ds_bpermute
+                    return V3{__int_as_float(__builtin_amdgcn_ds_bpermute(pix << 2, __float_as_int(d2.x))),
+                              __int_as_float(__builtin_amdgcn_ds_bpermute(pix << 2, __float_as_int(d2.y))),
+                              __int_as_float(__builtin_amdgcn_ds_bpermute(pix << 2, __float_as_int(d2.z)))};
+                }, lkey[wave]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const unsigned long long kb = lkey[wave][lane];
+                hit_idx = (kb == ~0ull) ? -1 : (int)(unsigned)(kb & 0xffffffffull);
+                closest = 0.0f;   // not used after the traversal
+              }
+            });
         } else if (x < p.nx && ly < p.row_count) {
             render_pixel<true>(p, x, ly, shade_n, state, rgb, true,
                          [&](V3 d2, float& closest, int& hit_idx) {
@@ -1464,11 +1566,10 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     }
     TiledWork w = *work;
     if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
-    // Waves that share a heavy tile: 8 when the launch has plenty of tiles per CU (throughput),
-    // 16 when it is small (a rank of a multi-GPU split): then the 64-sample chain of the densest
-    // tile bounds the time, so more tiles are shared (lower threshold) by more waves.
+    // Blocks of 8 waves share a heavy tile (16-wave blocks have no LDS left for the balanced walk and
+    // are slower at every launch size since it exists; kept for A/B through CRT_SHADE_GROUP).
     const int tiles_per_cu = w.tiles_total / std::max(n_cus, 1);
-    int dbg_repeat = 1, group = (tiles_per_cu >= 24) ? 8 : 16;
+    int dbg_repeat = 1, group = 8;
     int occ = (group == 8) ? 6 : 8;   // measured optimum with the LDS-staged light tiles
     if (const char* e = getenv("CRT_SHADE_OCC")) occ = atoi(e);                  // tuning hooks (not part of the ABI)
     if (const char* e = getenv("CRT_SHADE_GROUP")) group = atoi(e);              // waves that share a heavy tile
@@ -1482,9 +1583,9 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int);
     ShadeFn fn;
     if (group == 8) {
-        occ = (occ == 6 || occ == 4) ? occ : 8;
-        fn = vrec ? (occ == 6 ? shade_tiles_kernel<true, 6, 8> : occ == 4 ? shade_tiles_kernel<true, 4, 8> : shade_tiles_kernel<true, 8, 8>)
-                  : (occ == 6 ? shade_tiles_kernel<false, 6, 8> : occ == 4 ? shade_tiles_kernel<false, 4, 8> : shade_tiles_kernel<false, 8, 8>);
+        occ = (occ == 4) ? 4 : 6;   // 8 waves per SIMD do not fit the LDS of the staged variant
+        fn = vrec ? (occ == 6 ? shade_tiles_kernel<true, 6, 8> : shade_tiles_kernel<true, 4, 8>)
+                  : (occ == 6 ? shade_tiles_kernel<false, 6, 8> : shade_tiles_kernel<false, 4, 8>);
     } else {
         group = 16;
         occ = (occ == 4) ? 4 : 8;
