@@ -1161,9 +1161,10 @@ __device__ __forceinline__ void trace_pairs(StageArea& area, const int* ent, con
 // traces them against its own slice of the tile's list; the partial results meet in LDS as
 // 64-bit (ordered t, index) keys (atomicMin = the reference's accept rule); wave 0 shades.
 // Light tiles are then pulled one per wave from 64 interleaved chunks of the light queue
-// (one cursor per cache line).  VREC: the slice / list is staged in LDS and every lane walks
-// only the entries that can be hit from ITS pixel (stage_candidates / trace_candidates);
-// !VREC (variant 4, A/B): wave-uniform walks with scalar-operand records.
+// (one cursor per cache line).  VREC: the slice / list is staged in LDS, every lane classifies
+// the entries against ITS pixel (stage_candidates) and the surviving (pixel, entry) pairs are
+// walked evenly spread over the lanes (build_pairs / trace_pairs; trace_candidates when they
+// do not fit);  !VREC (variant 4, A/B): wave-uniform walks with scalar-operand records.
 template <bool VREC, int OCC, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
