@@ -12,6 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 L = _lib.lib()
 t0 = time.time()
+last_print = t0
 n_cases = n_audit_pairs = n_strip_cases = 0
 while time.time() - t0 < budget:
     rng = np.random.RandomState(seed)
@@ -71,4 +72,7 @@ while time.time() - t0 < budget:
         sys.exit(1)
     n_cases += 1
     seed += 1
+    if time.time() - last_print > 60:
+        print("  ... %d cases, %.0f s" % (n_cases, time.time() - t0), flush=True)
+        last_print = time.time()
 print("fuzz ok: %d cases (seeds up to %d), %d of them also as one rank's strips, %d audited passing pairs, %.0f s" % (n_cases, seed - 1, n_strip_cases, n_audit_pairs, time.time() - t0))
