@@ -631,7 +631,7 @@ constexpr int kRegionTilesX = kRegionW / 8, kRegionTilesY = kRegionH / 8;
 constexpr int kBinThreads = 64;
 constexpr int kBinWavesMin = 16384;   // the screen is cut into slices of region rows (blockIdx.y) / columns (blockIdx.z)
                                      // until the launch has this many wavefronts: few large triangles are not one wave's work
-constexpr int kFewTriangles = 16;    // a region with at most this many candidates is classified lane = tile
+constexpr int kFewTriangles = 8;     // a region with at most this many candidates is classified lane = tile (measured: 4..16 equal, 0 and 32+ slower)
 
 struct FormSet {          // the five affine forms of one triangle (dn, a, su, dq, w = a - su - dq)
     float A[5], B[5], C[5], M[5];
@@ -670,7 +670,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 template <int FILL>
 __global__ void __launch_bounds__(kBinThreads)
 bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledWork w,
-               unsigned long long* __restrict__ stats) {
+               unsigned long long* __restrict__ stats, int few_triangles) {
     unsigned n_region_hit = 0, n_tile_box = 0, n_tile_hit = 0;   // diagnostics (wave-uniform)
     const long long clk0 = stats ? (long long)clock64() : 0;
     const int tri = blockIdx.x * kBinThreads + threadIdx.x;
@@ -757,7 +757,7 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
             const unsigned long long m1 = __builtin_amdgcn_ballot_w64(s1);
             if (m1 == 0ull) continue;
             ++n_region_hit;
-            if (__builtin_popcountll(m1) <= kFewTriangles) {
+            if (__builtin_popcountll(m1) <= few_triangles) {
                 // few candidates: lane = tile of the region (16 x 4), one triangle at a time,
                 // broadcast from its lane.  Same arithmetic as below, so both passes and both
                 // modes select the same (tile, triangle) pairs.
@@ -928,15 +928,16 @@ static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int
     if (e != hipSuccess) return e;
     const int region_nx = (w.tiles_x + kRegionTilesX - 1) / kRegionTilesX, region_ny = (w.tiles_y + kRegionTilesY - 1) / kRegionTilesY;
     const int n_waves = (p.n_tris + kBinThreads - 1) / kBinThreads;
-    int waves_min = kBinWavesMin;
+    int waves_min = kBinWavesMin, few = kFewTriangles;
+    if (const char* ev = getenv("CRT_BIN_FEW")) few = atoi(ev);   // tuning hook
     if (const char* ev = getenv("CRT_BIN_WAVES")) waves_min = std::max(1, atoi(ev));   // tuning hook
     const int slices_y = std::max(1, std::min(region_ny, waves_min / std::max(n_waves, 1)));
     const int slices_x = std::max(1, std::min(region_nx, waves_min / std::max(n_waves * slices_y, 1)));
     const dim3 grid_tri((unsigned)n_waves, (unsigned)slices_y, (unsigned)slices_x);
-    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<0>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats);
+    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<0>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats, few);
     hipLaunchKernelGGL(bin_alloc_kernel, dim3((unsigned)((w.tiles_total + kAllocThreads - 1) / kAllocThreads)), dim3(kAllocThreads), 0, stream, w,
                        heavy_min, shade_blocks, d_stats);
-    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<1>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats);
+    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<1>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats, few);
     return hipGetLastError();
 }
 
