@@ -736,6 +736,14 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
         qt[k] = __builtin_fmaf(p.K_slack, f.M[k], __builtin_fmaf(hv_t, fabsf(f.C[k]), hu_t * fabsf(f.B[k])) * 1.0001f);
         qr[k] = __builtin_fmaf(p.K_slack, f.M[k], __builtin_fmaf(hv_r, fabsf(f.C[k]), hu_r * fabsf(f.B[k])) * 1.0001f);
     }
+    // the wavefront's forms as (A, B, C, q on a tile) + the tile-level box thresholds, for the lane = tile mode
+    __shared__ float4 sform[6][kBinThreads];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sform[k][lane] = make_float4(f.A[k], f.B[k], f.C[k], qt[k]);
+    sform[5][lane] = make_float4(tu_lo, tu_hi, tv_lo, tv_hi);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float c[5];
     for (int ry = ry_lo; ry < ry_hi; ++ry) {
         // 32 local rows: inside one strip, so the region's global rows are contiguous
@@ -772,12 +780,13 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
                     const int src = (int)__builtin_ctzll(mm);
                     float q5[5];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        c[k] = __builtin_fmaf(uct, lane_bcast(f.B[k], src), __builtin_fmaf(vct, lane_bcast(f.C[k], src), lane_bcast(f.A[k], src)));
-                        q5[k] = lane_bcast(qt[k], src);
+                    for (int k = 0; k < 5; ++k) {   // broadcast LDS reads: VGPR operands (readlane would feed the VALU through SGPRs)
+                        const float4 fk = sform[k][src];
+                        c[k] = __builtin_fmaf(uct, fk.y, __builtin_fmaf(vct, fk.z, fk.x));
+                        q5[k] = fk.w;
                     }
-                    const bool s2 = tile_ok && !(vct < lane_bcast(tv_lo, src)) && !(vct > lane_bcast(tv_hi, src)) &&
-                                    !(uct < lane_bcast(tu_lo, src)) && !(uct > lane_bcast(tu_hi, src)) && cell_may_hit(c, q5);
+                    const float4 bx = sform[5][src];   // tu_lo, tu_hi, tv_lo, tv_hi
+                    const bool s2 = tile_ok && !(vct < bx.z) && !(vct > bx.w) && !(uct < bx.x) && !(uct > bx.y) && cell_may_hit(c, q5);
                     n_tile_box += 64u;
                     if (s2) {
                         const unsigned tri_src = (unsigned)(blockIdx.x * kBinThreads + src);
