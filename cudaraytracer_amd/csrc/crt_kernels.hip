@@ -660,10 +660,6 @@ __device__ __forceinline__ bool cell_may_hit(const float c[5], const float q[5])
     return cull_ok && (pos || neg);
 }
 
-__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
-}
-
 // FILL 0: count the survivors of every tile.  FILL 1 (after bin_alloc_kernel): write them.
 // Control flow is wave-uniform (ballots), so every tile costs one atomic per wavefront that
 // touches it.
