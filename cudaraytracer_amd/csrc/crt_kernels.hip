@@ -1224,7 +1224,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool lane_valid = xr < hx1 && lyr < hly1;
             const int x = min(xr, hx1 - 1), ly = min(lyr, hly1 - 1);   // lanes off the image replay a valid pixel
             // Master/worker: wave 0 owns the pixels' RNG streams, generates the 64 rays of each
-            // sample and shades; the other 15 waves only trace.  Two barriers per sample:
+            // sample and shades; the other waves only trace.  Two barriers per sample:
             // B1 "rays are in LDS", B2 "partial minima are in LDS".
             // this wave's slice: the first 64 entries are staged in LDS like a light tile's list
             const int n_lds = (VREC && !walk_all) ? min(64, k1 - k0) : 0;
