@@ -28,8 +28,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FRAME = "C3"                                # cudaraytracer_amd.scenes.BASELINE_FRAMES: the definition the tests share
 NX, NY, SPP = 1920, 1080, 64
-N_LAT, N_LON = 200, 250                     # 100 000 triangles
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 REC_BYTES = 64                              # derived triangle record (csrc/crt_device.hpp)
 CLS_BYTES = 80                              # classification record: 5 float4 planes
@@ -37,10 +37,11 @@ BASE_BYTES = 48                             # per-triangle input of tri_prepass:
 
 
 def build_scene_obj(tmpdir):
+    """The timed frame = scenes.baseline_obj("C3"): the frame tests/test_gpu_configs.py checks
+    against the brute-force walk and the oracle at the full 64 spp."""
     from cudaraytracer_amd import scenes
-    sc = scenes.displaced_sphere(N_LAT, N_LON, radius=200.0, centre=(0.0, 0.0, 0.0), index_base=1)
-    path = os.path.join(tmpdir, "bunny100k_synthetic.obj")
-    scenes.write_obj(path, sc)
+    path, nx, ny, spp = scenes.baseline_obj(FRAME, tmpdir)
+    assert (nx, ny, spp) == (NX, NY, SPP)
     return path
 
 
@@ -76,7 +77,7 @@ def cpu_baseline(obj_path, budget_rays=1536):
     cam = po.make_camera((0, 100, 1000), (0, 150, 0), (0, 1, 0), 40.0,
                          np.float32(NX) / np.float32(NY), 0.0, 10.0)
     cw, ch, cs = 32, 12, 4                  # 32x12 px x 4 spp = 1536 rays x 100 k triangles
-    r0, c0 = NY // 2 - ch // 2, NX // 2 - cw // 2
+    r0, c0 = 500, NX // 2 - 250             # on the mesh, near its left silhouette (the mesh covers rows ~20..620)
     win = (r0, r0 + ch, c0, c0 + cw)
     po.render(w, cam, NX, NY, 1, window=(r0, r0 + 1, c0, c0 + 2))      # warm caches / tables
     import ctypes as C
@@ -87,13 +88,26 @@ def cpu_baseline(obj_path, budget_rays=1536):
         first = y * NX + c0
         L.o_set_curand_state_range(states[first:].ctypes.data, first, cw, 0)
     t0 = time.perf_counter()
-    po.render(w, cam, NX, NY, cs, window=win, states=states)
+    ref, _ = po.render(w, cam, NX, NY, cs, window=win, states=states)
     dt = time.perf_counter() - t0
     rays = cw * ch * cs
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": "oracle/crt_oracle.c (gcc -O2, 1 thread), centred %dx%d px crop x %d spp of the "
-                      "1920x1080 frame against all %d triangles: %d rays in %.1f s"
-                      % (cw, ch, cs, w.n_tris, rays, dt)}
+            "sample": "oracle/crt_oracle.c (gcc -O2, 1 thread), %dx%d px crop (rows %d.., columns %d.., on the mesh) x %d spp "
+                      "of the 1920x1080 frame against all %d triangles: %d rays in %.1f s"
+                      % (cw, ch, r0, c0, cs, w.n_tris, rays, dt)}, win, cs, ref[r0:r0 + ch, c0:c0 + cw]
+
+
+def hip_crop(scene, camera, win, spp):
+    """The same crop through the product: fresh RNG states of the crop's rows (seed 0, stream =
+    global pixel index), crt_render_rows at `spp`, columns cut on the host."""
+    import torch
+    from cudaraytracer_amd import api
+    r0, r1, c0, c1 = win
+    st = api.SetCurandState(NX, NY, 0, r0, r1 - r0)
+    d = torch.zeros((r1 - r0) * NX * 3, dtype=torch.float32, device="cuda")
+    api.render_rows(scene, camera, st, NX, NY, spp, r0, r1 - r0, d, stream=torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    return d.cpu().numpy().reshape(r1 - r0, NX, 3)[:, c0:c1]
 
 
 def main():
@@ -186,6 +200,30 @@ def main():
     st = api.tiled_stats(False)
     tiled = st[4] > 0
 
+    # The headline depends on what the frame shows (the tiled kernels skip what no ray can hit;
+    # the brute-force walk did not): the same mesh seen from 300 units fills the whole screen.
+    filling = None
+    if rank == 0 and world == 1 and tiled:
+        cam_near = api.create_camera(NX, NY, (0.0, 0.0, 300.0), (0.0, 0.0, 0.0), 10.0, 0.0, 40)
+        st_near = api.SetCurandState(NX, NY, 0)
+        buf = torch.empty(NX * NY * 3, dtype=torch.float32, device="cuda")
+        api.tiled_stats(True)
+        api.render_rows(scene, cam_near, st_near, NX, NY, args.spp, 0, NY, buf, stream=stream)
+        torch.cuda.synchronize()
+        st_n = api.tiled_stats(False)
+        for _ in range(3):
+            api.render_rows(scene, cam_near, st_near, NX, NY, args.spp, 0, NY, buf, stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            api.render_rows(scene, cam_near, st_near, NX, NY, args.spp, 0, NY, buf, stream=stream)
+        torch.cuda.synchronize()
+        ms_near = (time.perf_counter() - t1) / 10 * 1e3
+        filling = {"camera": "lookfrom (0,0,300) lookat (0,0,0): the mesh covers every pixel",
+                   "ms_per_frame": ms_near, "Mrays/s": NX * NY * args.spp / ms_near / 1e3,
+                   "tiles_with_geometry_frac": 1.0 - st_n[8] / max(st_n[4], 1),
+                   "tile_survivors_sum": st_n[5], "tile_survivors_max": st_n[6]}
+
     if rank == 0:
         rays = NX * NY * args.spp * args.steps
         value = rays / elapsed / 1e6
@@ -194,7 +232,7 @@ def main():
             bin_b, shade_b = algorithmic_bytes_tiled(NX, br.row_count, args.spp, n_tris, BASE_BYTES, st[5])
             kernels = {
                 "binning": {"ms": k_bin, "algorithmic_bytes": bin_b, "GB/s": bin_b / (k_bin * 1e-3) / 1e9,
-                            "note": "tri_prepass + cls_prepass + bin_tri_kernel<count> + bin_alloc_kernel + "
+                            "note": "per-frame prepass + bin_tri_kernel<count> + bin_alloc_kernel + "
                                     "bin_tri_kernel<fill>: lane = triangle, one coalesced pass each over the "
                                     "per-triangle records; launch-latency bound at this size"},
                 "shade_tiles_kernel": {"ms": k_shade, "algorithmic_bytes": shade_b,
@@ -205,29 +243,34 @@ def main():
             dom = "shade_tiles_kernel" if k_shade >= k_bin else "binning"
             alg, k_ms = kernels[dom]["algorithmic_bytes"], kernels[dom]["ms"]
             survivors = {"bin_wavefronts": st[0], "regions_entered": st[1], "tiles": st[4],
-                         "tile_survivors_sum": st[5], "tile_survivors_max": st[6], "pool_overflows": st[7]}
+                         "tile_survivors_sum": st[5], "tile_survivors_max": st[6], "pool_overflows": st[7],
+                         "tiles_with_geometry_frac": 1.0 - st[8] / max(st[4], 1)}
         else:
             alg, k_ms, dom = algorithmic_bytes_brute(NX, br.row_count, args.spp, n_tris), k_tot, "render_list_kernel"
             kernels, survivors = {"render_list_kernel": {"ms": k_tot, "algorithmic_bytes": alg}}, None
         achieved = alg / (k_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this very
-        # command (tools/profile_bench.sh; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE)
+        # HBM traffic and VALU instruction count of the dominant kernel: NOT from this run — from the
+        # committed rocprofv3 PMC passes of this very command (tools/profile_bench.sh; the summary
+        # names the commit it was taken at).  The kernel time they are divided by IS this run's.
         traffic, traffic_src, valu = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r1_tiled", "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin_fill"))
+        for prof in ("r2_tiled", "r1_tiled"):
+            pmc = os.path.join(ROOT, "profiles", prof, "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin_fill"))
+            if os.path.exists(pmc):
+                break
         if tiled and world == 1 and args.spp == SPP and os.path.exists(pmc):
             try:
                 summary = json.load(open(pmc))
                 traffic = summary["derived"]["hbm_traffic_bytes_corrected"]
-                traffic_src = os.path.relpath(pmc, ROOT)
-                # what actually bounds the kernel: VALU issue.  SQ_INSTS_VALU per launch (rocprofv3 PMC
-                # pass) over this run's kernel time; peak = 1 wave64 VALU instruction per 2.25 cycles per
-                # SIMD, measured on this chip for VGPR-only v_mul/v_add (profiles/r1_ubench_valu2.txt)
+                traffic_src = "prior rocprofv3 --pmc pass of this command: %s" % os.path.relpath(pmc, ROOT)
+                # what actually bounds the kernel: VALU issue.  SQ_INSTS_VALU per launch over this run's
+                # kernel time; peak = 1 wave64 VALU instruction per 2.25 cycles per SIMD, measured on
+                # this chip for VGPR-only v_mul/v_add (profiles/r1_ubench_valu2.txt)
                 insts = summary["per_launch_counters"].get("SQ_INSTS_VALU")
                 if insts:
                     rate = insts / (k_ms * 1e-3) / 1024 / 2.4e9
                     valu = {"unit": "wave64 VALU instructions per clock per SIMD", "achieved": rate,
                             "peak": 1 / 2.25, "frac": rate * 2.25, "insts_per_launch": insts,
-                            "source": os.path.relpath(pmc, ROOT)}
+                            "source": traffic_src}
             except Exception:
                 traffic = None
         out = {
@@ -240,19 +283,30 @@ def main():
                                    "(displaced sphere; bunny.obj is absent from the reference), "
                                    "triangle list (HitableList path), reference camera" % (NX, NY, args.spp, n_tris),
                        "nx": NX, "ny": NY, "spp": args.spp, "triangles": n_tris,
-                       "parallelism": "row-bands x%d + 1 gather" % world,
+                       "parallelism": ("1 GPU, one launch" if world == 1 else
+                                       "32-row strips dealt round-robin x%d + 1 gather to rank 0 + reassembly kernel" % world),
                        "kernel_variant": args.variant},
-            "ray_triangle_pairs_per_s": value * 1e6 * n_tris,
+            # rays x triangles: what the reference's list walk would test, NOT what the tiled kernels
+            # execute (they test `tile_survivors_sum` list entries per sample and tile)
+            "nominal_list_pairs_per_s": value * 1e6 * n_tris,
             "kernel_ms": k_tot,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": dom, "algorithmic_bytes_per_launch": alg},
+                         "kernel": dom, "algorithmic_bytes_per_launch": alg,
+                         "limiter": "valu issue, not HBM: see valu_issue (DESIGN.md §5)"},
             "valu_issue": valu,
             "kernels": kernels,
             "survivors": survivors,
+            "screen_filling_variant": filling,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(obj_path)
+            base, win, cs, ref = cpu_baseline(obj_path)
+            out["cpu_baseline"] = base
+            # the same crop through the product, outside the timed region: the frame that is timed is
+            # the frame that is checked (bit-exact against the oracle)
+            got = hip_crop(scene, camera, win, cs)
+            out["parity_crop"] = bool(np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(ref).view(np.uint32)))
+            out["parity_crop_hit_pixels"] = int(((ref[..., 0] - ref[..., 2]) > 0.05).sum())
         print(json.dumps(out), flush=True)
 
     if world > 1:

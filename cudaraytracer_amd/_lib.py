@@ -77,6 +77,17 @@ PROTOTYPES = {
                                         C.POINTER(C.c_uint64)]),
     "crt_last_kernel_ms": (C.c_float, []),
     "crt_last_kernel_times": (C.c_int, [C.POINTER(C.c_float)]),
+    "crt_strip_part_stride": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "crt_assemble_strips": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "crt_gather_strips": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "crt_multi_create": (C.c_void_p, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_uint64, C.c_int]),
+    "crt_multi_render": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_int, C.c_int, C.c_int, _fp]),
+    "crt_multi_update_pose": (C.c_int, [C.c_void_p, _fp, C.c_int]),
+    "crt_multi_frame": (C.c_void_p, [C.c_void_p]),
+    "crt_multi_device_count": (C.c_int, [C.c_void_p]),
+    "crt_multi_free": (None, [C.c_void_p]),
+    "crt_write_png_rgba8": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "crt_to_rgba8": (None, [_fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "crt_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _fp]),
 }

@@ -192,6 +192,70 @@ def render_strips(scene, camera, curand_state, nx, ny, samples, first_strip, str
                                        C.c_void_p(ptr), C.c_void_p(sptr)))
 
 
+def strip_part_stride(nx, ny, strip_rows_, world):
+    return _lib.lib().crt_strip_part_stride(nx, ny, strip_rows_, world)
+
+
+def assemble_strips(d_parts, part_stride, nx, ny, strip_rows_, world, d_full, stream=None):
+    """crt_assemble_strips: the root's reassembly kernel (rank r's strips start at
+    d_parts + r*part_stride floats; d_full receives the nx x ny float3 frame)."""
+    pp = d_parts if isinstance(d_parts, int) else d_parts.data_ptr()
+    pf = d_full if isinstance(d_full, int) else d_full.data_ptr()
+    sptr = None
+    if stream is not None:
+        sptr = stream if isinstance(stream, int) else stream.cuda_stream
+    check(_lib.lib().crt_assemble_strips(C.c_void_p(pp), int(part_stride), nx, ny, strip_rows_, world,
+                                         C.c_void_p(pf), C.c_void_p(sptr)))
+
+
+def gather_strips(d_piece, nx, ny, strip_rows_, rank, world, d_parts, part_stride, d_full, nccl_comm, stream=None):
+    """crt_gather_strips: grouped RCCL send/recv of the pieces to rank 0 + reassembly there.
+    nccl_comm: the caller's ncclComm_t as an integer."""
+    def ptr(t):
+        return None if t is None else C.c_void_p(t if isinstance(t, int) else t.data_ptr())
+    sptr = None
+    if stream is not None:
+        sptr = stream if isinstance(stream, int) else stream.cuda_stream
+    check(_lib.lib().crt_gather_strips(ptr(d_piece), nx, ny, strip_rows_, rank, world, ptr(d_parts), int(part_stride),
+                                       ptr(d_full), C.c_void_p(nccl_comm), C.c_void_p(sptr)))
+
+
+class MultiRenderer:
+    """crt_multi_*: one process driving n_gpus devices (ncclCommInitAll, one stream and one
+    host worker per device): replicated scene, strips dealt round-robin, one grouped RCCL
+    send/recv, reassembly on device 0."""
+
+    def __init__(self, points, idx3f, normals, index_base, nx, ny, n_gpus, seed=0, albedo=DEFAULT_ALBEDO):
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(idx3f, dtype=np.float32).reshape(-1, 3)
+        nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        alb = np.array(albedo, dtype=np.float32)
+        self.nx, self.ny = nx, ny
+        self.handle = check_handle(_lib.lib().crt_multi_create(
+            _fp(pts), len(pts), _fp(idx), len(idx), None if nrm is None else _fp(nrm), int(index_base), _fp(alb),
+            nx, ny, int(seed), int(n_gpus)))
+
+    def render(self, camera, samples, max_depth=8, frame_index=0):
+        out = np.zeros((self.ny, self.nx, 3), dtype=np.float32)
+        check(_lib.lib().crt_multi_render(self.handle, C.byref(camera.c), samples, max_depth, frame_index, _fp(out)))
+        return out
+
+    def update_pose(self, new_points):
+        pts = np.ascontiguousarray(new_points, dtype=np.float32).reshape(-1, 3)
+        check(_lib.lib().crt_multi_update_pose(self.handle, _fp(pts), len(pts)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().crt_multi_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def last_kernel_ms():
     ms = _lib.lib().crt_last_kernel_ms()
     if ms < 0:

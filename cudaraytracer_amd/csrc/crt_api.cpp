@@ -28,15 +28,10 @@
 #endif
 
 namespace {
-
 thread_local std::string g_err;
-thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr, g_ev_mid = nullptr;
-thread_local bool g_ev_has_mid = false;
-thread_local bool g_ev_valid = false;
-thread_local int g_variant = 0;
-thread_local unsigned long long* g_d_stats = nullptr;   // device counters when stats are enabled
+}
 
-int fail(int code, const char* fmt, ...) {
+int crt::set_error(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -46,6 +41,13 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace {
+
+thread_local int g_variant = 0;
+thread_local unsigned long long* g_d_stats = nullptr;   // device counters when stats are enabled
+
+#define fail(...) crt::set_error(__VA_ARGS__)
+
 #define HIP_TRY(expr)                                                                  \
     do {                                                                               \
         hipError_t e_ = (expr);                                                        \
@@ -54,24 +56,64 @@ int fail(int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                           \
     } while (0)
 
-// Scratch of the tiled variant: per host thread, grow-only, reused by every frame.
-struct Workspace {
+// Launch context: everything a render launch writes besides its outputs — the per-frame derived
+// triangle records (exact + classification), the scratch of the tiled variant, the timing events,
+// the cached occupancy — lives here, one context per (device, stream).  Work enqueued on one
+// stream is ordered by the stream, so launches of one context never overlap; launches on
+// different streams or devices use different contexts and share nothing but read-only scene data.
+// Grow-only; freed at process exit.
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                   // host-side: two threads enqueueing on the same stream
     crt::TiledWork w{};
     size_t pool_entries = 0, tiles = 0;
     int n_cus = 0;
+    float* d_rec = nullptr;          // n x 16 derived records (tri_prepass output)
+    float4* d_cls = nullptr;         // 5 planes x n_pad classification records (cls_prepass output)
+    size_t rec_cap = 0, cls_cap = 0; // in triangles
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
+    bool ev_has_mid = false, ev_valid = false;
+    crt::LaunchCache cache;
 };
-thread_local Workspace g_ws;
+std::mutex g_ctx_mu;
+std::vector<Context*> g_contexts;
+thread_local Context* g_last_ctx = nullptr;   // crt_last_kernel_ms / crt_last_kernel_times: last launch of this thread
 
-int ensure_workspace(int nx, int rows) {
-    Workspace& ws = g_ws;
+Context* context_for(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    for (Context* c : g_contexts)
+        if (c->device == device && c->stream == stream) return c;
+    Context* c = new (std::nothrow) Context;
+    if (!c) return nullptr;
+    c->device = device;
+    c->stream = stream;
+    g_contexts.push_back(c);
+    return c;
+}
+
+int ensure_records(Context& cx, int n_tris, int n_pad) {
+    const size_t want = (size_t)std::max(n_tris, 1), want_pad = (size_t)std::max(n_pad, 64);
+    if (want > cx.rec_cap) {
+        if (cx.d_rec) (void)hipFree(cx.d_rec);
+        cx.d_rec = nullptr; cx.rec_cap = 0;
+        HIP_TRY(hipMalloc(&cx.d_rec, want * crt::kRecFloats * sizeof(float)));
+        cx.rec_cap = want;
+    }
+    if (want_pad > cx.cls_cap) {
+        if (cx.d_cls) (void)hipFree(cx.d_cls);
+        cx.d_cls = nullptr; cx.cls_cap = 0;
+        HIP_TRY(hipMalloc(&cx.d_cls, (size_t)crt::kClsPlanes * want_pad * sizeof(float4)));
+        cx.cls_cap = want_pad;
+    }
+    return CRT_OK;
+}
+
+int ensure_workspace(Context& ws, int nx, int rows) {
     const int tiles_x = (nx + 7) / 8, tiles_y = (rows + 7) / 8;
     const size_t tiles = (size_t)tiles_x * tiles_y;
     const size_t want_pool = std::min<size_t>(std::max<size_t>((size_t)16 << 20, tiles * 256), (size_t)1 << 30);
-    if (!ws.n_cus) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&ws.n_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    if (!ws.n_cus) HIP_TRY(hipDeviceGetAttribute(&ws.n_cus, hipDeviceAttributeMultiprocessorCount, ws.device));
     if (!ws.w.counters) {
         HIP_TRY(hipMalloc(&ws.w.counters, crt::kCtrWords * sizeof(uint32_t)));
         ws.w.counters64 = reinterpret_cast<unsigned long long*>(ws.w.counters);
@@ -79,6 +121,7 @@ int ensure_workspace(int nx, int rows) {
     if (want_pool > ws.pool_entries) {
         if (ws.w.pool) (void)hipFree(ws.w.pool);
         ws.w.pool = nullptr;
+        ws.pool_entries = 0;
         HIP_TRY(hipMalloc(&ws.w.pool, want_pool * sizeof(uint32_t)));
         ws.pool_entries = want_pool;
     }
@@ -89,6 +132,7 @@ int ensure_workspace(int nx, int rows) {
         ws.w.queue = nullptr;
         if (ws.w.tile_count) (void)hipFree(ws.w.tile_count);
         ws.w.tile_count = nullptr;
+        ws.tiles = 0;
         HIP_TRY(hipMalloc(&ws.w.tile_desc, tiles * sizeof(uint2)));
         HIP_TRY(hipMalloc(&ws.w.queue, crt::kClasses * tiles * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&ws.w.tile_count, tiles * sizeof(uint32_t)));
@@ -258,13 +302,13 @@ struct crt_scene {
     float albedo[3] = {0, 0, 0};
     float* d_base = nullptr;      // n x 12: v0 v1 v2 n
     float* d_shade_n = nullptr;   // n x 3: normal after the two rotate() calls of Hitable::hit
-    float* d_rec = nullptr;       // n x 16 derived records (prepass output)
-    float4* d_cls = nullptr;      // 4 planes x n_pad classification records (tiled variant)
-    int n_pad = 0;
+    int n_pad = 0;                // triangle count rounded up to 64 (plane stride of the classification records)
     bool tiled_safe = false;      // all coordinates finite and |c| <= 2^38
     int n_points = 0;             // update_pose: size of the point array the indices refer to
     int* d_idx = nullptr;         // n x 3 vertex indices, 0-based (as given: idx[0], idx[1], idx[2])
     float* d_points = nullptr;    // n_points x 3 staging of the current pose
+    float* h_points = nullptr;    // pinned host copy of the caller's array (the caller's buffer is free again on return)
+    hipEvent_t pose_copied = nullptr;   // the last H2D copy out of h_points has finished
 };
 
 struct crt_rng {
@@ -374,8 +418,6 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
     size_t nalloc = (size_t)std::max(n_tris, 1);
     if (e == hipSuccess) e = hipMalloc(&s->d_base, nalloc * crt::kBaseFloats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&s->d_shade_n, nalloc * 3 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&s->d_rec, nalloc * crt::kRecFloats * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&s->d_cls, (size_t)crt::kClsPlanes * s->n_pad * sizeof(float4));
     s->n_points = n_points;
     if (e == hipSuccess) e = hipMalloc(&s->d_idx, nalloc * 3 * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(s->d_idx, idx0.data(), nalloc * 3 * sizeof(int), hipMemcpyHostToDevice);
@@ -390,35 +432,53 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
 }
 
 int crt_parse_obj(const char* path, float* points, float* idx3f, int* n_points, int* n_tris) {
+    // parseObjByName (Loader/obj_loader.h:20-111) reads `v x y z` and `f a b c` with `ss >> float`
+    // and nothing else; files it can read give the same arrays here.  Beyond it (SURVEY §8f rank 4,
+    // a deliberate extension — the reference's extraction stops at the first '/'): face tokens
+    // `a/b`, `a//c`, `a/b/c` (the leading vertex index is used), negative (relative) indices, and
+    // polygons with more than three vertices (fan: (v0, vk, vk+1)), which is what makes
+    // CudaTest/objects/cbox_smallbox.obj and Meshlab/Blender exports loadable.
     if (!path || !n_points || !n_tris) return fail(CRT_ERR_INVALID, "crt_parse_obj: null argument");
     FILE* f = fopen(path, "r");
     if (!f) return fail(CRT_ERR_IO, "crt_parse_obj: cannot open %s", path);
     int np = 0, nt = 0;
-    char line[2048];
-    auto three = [](const char* p, float out[3]) {
-        // `ss >> a >> b >> c` on floats (Loader/obj_loader.h:49,62): leading number of each token
-        for (int k = 0; k < 3; ++k) {
-            while (*p == ' ' || *p == '\t') ++p;
-            char* end = nullptr;
-            out[k] = strtof(p, &end);
-            if (end == p) { out[k] = 0.0f; return; }
-            p = end;
-            while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') ++p;   // skip "/vt/vn"
-        }
-    };
+    char line[4096];
+    std::vector<float> face;
     while (fgets(line, sizeof line, f)) {
         const char* p = line;
         while (*p == ' ' || *p == '\t') ++p;
         if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
             float v[3] = {0, 0, 0};
-            three(p + 1, v);
+            p += 1;
+            for (int k = 0; k < 3; ++k) {   // `ss >> point[0] >> point[1] >> point[2]`, obj_loader.h:49
+                char* end = nullptr;
+                v[k] = strtof(p, &end);
+                if (end == p) { v[k] = 0.0f; break; }
+                p = end;
+            }
             if (points) memcpy(points + 3 * (size_t)np, v, sizeof v);
             ++np;
         } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
-            float v[3] = {0, 0, 0};
-            three(p + 1, v);
-            if (idx3f) memcpy(idx3f + 3 * (size_t)nt, v, sizeof v);   // kept as floats, 1-based
-            ++nt;
+            face.clear();
+            p += 1;
+            for (;;) {
+                while (*p == ' ' || *p == '\t') ++p;
+                char* end = nullptr;
+                float a = strtof(p, &end);
+                if (end == p) break;
+                if (a < 0.0f) a = (float)np + a + 1.0f;   // relative index: -1 is the latest vertex
+                face.push_back(a);                        // kept as floats, 1-based (obj_loader.h:62-64)
+                p = end;
+                while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') ++p;   // skip "/vt/vn"
+            }
+            while (face.size() < 3) face.push_back(0.0f);   // a failed extraction leaves 0 (C++11 operator>>)
+            for (size_t k = 1; k + 1 < face.size(); ++k) {
+                if (idx3f) {
+                    float* o = idx3f + 3 * (size_t)nt;
+                    o[0] = face[0]; o[1] = face[k]; o[2] = face[k + 1];
+                }
+                ++nt;
+            }
         }
     }
     fclose(f);
@@ -459,8 +519,21 @@ int crt_scene_update_pose(crt_scene* s, const float* new_points, int n_points, v
         finite = finite && std::isfinite(new_points[k]);
         max_abs = std::max(max_abs, fabsf(new_points[k]));
     }
-    if (!s->d_points) HIP_TRY(hipMalloc(&s->d_points, (size_t)n_points * 3 * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(s->d_points, new_points, (size_t)n_points * 3 * sizeof(float), hipMemcpyHostToDevice, stream));
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    if (device != s->device)
+        return fail(CRT_ERR_INVALID, "crt_scene_update_pose: current device is %d, the scene lives on device %d", device, s->device);
+    const size_t bytes = (size_t)n_points * 3 * sizeof(float);
+    if (!s->d_points) HIP_TRY(hipMalloc(&s->d_points, bytes));
+    if (!s->h_points) {
+        HIP_TRY(hipHostMalloc(&s->h_points, bytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&s->pose_copied, hipEventDisableTiming));
+    } else {
+        HIP_TRY(hipEventSynchronize(s->pose_copied));   // the previous pose has left the staging buffer
+    }
+    memcpy(s->h_points, new_points, bytes);
+    HIP_TRY(hipMemcpyAsync(s->d_points, s->h_points, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(s->pose_copied, stream));
     HIP_TRY(crt::launch_update_pose(s->d_points, s->d_idx, s->n_tris, s->d_base, stream));
     s->tiled_safe = finite && max_abs <= 274877906944.0f;   // 2^38, as at creation (here over all points)
     return CRT_OK;
@@ -472,10 +545,10 @@ void crt_scene_free(crt_scene* s) {
     if (!s) return;
     if (s->d_base) (void)hipFree(s->d_base);
     if (s->d_shade_n) (void)hipFree(s->d_shade_n);
-    if (s->d_rec) (void)hipFree(s->d_rec);
-    if (s->d_cls) (void)hipFree(s->d_cls);
     if (s->d_idx) (void)hipFree(s->d_idx);
     if (s->d_points) (void)hipFree(s->d_points);
+    if (s->h_points) (void)hipHostFree(s->h_points);
+    if (s->pose_copied) (void)hipEventDestroy(s->pose_copied);
     delete s;
 }
 
@@ -622,14 +695,28 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         return fail(CRT_ERR_INVALID, "crt_render_rows: rng covers pixels [%lld,+%lld) step %d, the rows need [%lld,+%lld) step %d",
                     rng->first, rng->count, rng->strip_step, first, count, strip_step);
     hipStream_t stream = (hipStream_t)stream_;
-
-    if (!g_ev_start) {
-        HIP_TRY(hipEventCreate(&g_ev_start));
-        HIP_TRY(hipEventCreate(&g_ev_stop));
-        HIP_TRY(hipEventCreate(&g_ev_mid));
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    if (scene->device != device || rng->device != device)
+        return fail(CRT_ERR_INVALID, "crt_render_rows: current device is %d but the scene lives on device %d and the RNG states on device %d",
+                    device, scene->device, rng->device);
+    Context* cxp = context_for(device, stream);
+    if (!cxp) return fail(CRT_ERR_NOMEM, "crt_render_rows: out of memory");
+    Context& cx = *cxp;
+    std::lock_guard<std::mutex> lock(cx.mu);
+    g_last_ctx = cxp;
+    {
+        int rc = ensure_records(cx, scene->n_tris, scene->n_pad);
+        if (rc != CRT_OK) return rc;
     }
-    HIP_TRY(hipEventRecord(g_ev_start, stream));   // the per-frame prepasses count as binning time
-    HIP_TRY(crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, scene->d_rec, stream));
+
+    if (!cx.ev_start) {
+        HIP_TRY(hipEventCreate(&cx.ev_start));
+        HIP_TRY(hipEventCreate(&cx.ev_stop));
+        HIP_TRY(hipEventCreate(&cx.ev_mid));
+    }
+    HIP_TRY(hipEventRecord(cx.ev_start, stream));   // the per-frame prepasses count as binning time
+    HIP_TRY(crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, cx.d_rec, stream));
 
     // public variant numbering (crt_set_kernel_variant): 0 auto, 1 brute force, 2 tiled,
     // 3 tiled with tiny list capacities (exercises the overflow fallbacks)
@@ -662,16 +749,16 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
 
     if (kernel_variant != 0) {
-        int rc = ensure_workspace(nx, row_count);
+        int rc = ensure_workspace(cx, nx, row_count);
         if (rc != CRT_OK) return rc;
-        HIP_TRY(crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p, scene->d_cls, stream));
+        HIP_TRY(crt::launch_cls_prepass(cx.d_rec, scene->n_tris, scene->n_pad, p, cx.d_cls, stream));
     }
-    HIP_TRY(crt::launch_render(p, scene->d_rec, scene->d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
-                               d_rgb, kernel_variant, kernel_variant ? &g_ws.w : nullptr, g_ws.n_cus,
-                               scene->tiled_safe && cam_ok, g_d_stats, kernel_variant ? g_ev_mid : nullptr, stream));
-    g_ev_has_mid = kernel_variant != 0;
-    HIP_TRY(hipEventRecord(g_ev_stop, stream));
-    g_ev_valid = true;
+    HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
+                               d_rgb, kernel_variant, kernel_variant ? &cx.w : nullptr, cx.n_cus,
+                               scene->tiled_safe && cam_ok, g_d_stats, kernel_variant ? cx.ev_mid : nullptr, &cx.cache, stream));
+    cx.ev_has_mid = kernel_variant != 0;
+    HIP_TRY(hipEventRecord(cx.ev_stop, stream));
+    cx.ev_valid = true;
     return CRT_OK;
 }
 }  // namespace
@@ -702,12 +789,18 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     p.rny = 1.0f / (float)ny;
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
     unsigned long long* d = nullptr;
-    int rc = ensure_workspace(nx, ny);
+    int device = 0;
+    Context* cxp = (hipGetDevice(&device) == hipSuccess) ? context_for(device, nullptr) : nullptr;
+    if (!cxp) { crt_rng_free(rng); return fail(CRT_ERR_HIP, "crt_debug_audit_tiles: no launch context"); }
+    Context& cx = *cxp;
+    std::lock_guard<std::mutex> lock(cx.mu);
+    int rc = ensure_workspace(cx, nx, ny);
+    if (rc == CRT_OK) rc = ensure_records(cx, scene->n_tris, scene->n_pad);
     hipError_t e = (rc == CRT_OK) ? hipMalloc(&d, 4 * sizeof(unsigned long long)) : hipErrorUnknown;
     if (e == hipSuccess) e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, scene->d_rec, nullptr);
-    if (e == hipSuccess) e = crt::launch_cls_prepass(scene->d_rec, scene->n_tris, scene->n_pad, p, scene->d_cls, nullptr);
-    if (e == hipSuccess) e = crt::launch_audit(p, scene->d_rec, scene->d_cls, scene->n_pad, rng->d_state, &g_ws.w, d, nullptr);
+    if (e == hipSuccess) e = crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, cx.d_rec, nullptr);
+    if (e == hipSuccess) e = crt::launch_cls_prepass(cx.d_rec, scene->n_tris, scene->n_pad, p, cx.d_cls, nullptr);
+    if (e == hipSuccess) e = crt::launch_audit(p, cx.d_rec, cx.d_cls, scene->n_pad, rng->d_state, &cx.w, d, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     unsigned long long h[4] = {0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
@@ -775,28 +868,28 @@ int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t* mismatc
 }
 
 int crt_last_kernel_times(float* ms3) {
-    // ms3[0] = all render kernels of the last crt_render_rows, ms3[1] = binning kernel,
-    // ms3[2] = shading kernel (tiled variant) or the brute-force kernel; HIP events on the
-    // launch stream.
+    // ms3[0] = all render kernels of the last crt_render_rows of this thread, ms3[1] = prepasses +
+    // binning, ms3[2] = shading kernel (tiled variant) or the brute-force kernel; HIP events on the
+    // launch stream of that call.
     if (!ms3) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: null output");
-    if (!g_ev_valid) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: no kernel launched on this thread");
-    HIP_TRY(hipEventSynchronize(g_ev_stop));
-    HIP_TRY(hipEventElapsedTime(&ms3[0], g_ev_start, g_ev_stop));
+    Context* cx = g_last_ctx;
+    if (!cx || !cx->ev_valid) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: no kernel launched on this thread");
+    std::lock_guard<std::mutex> lock(cx->mu);
+    HIP_TRY(hipEventSynchronize(cx->ev_stop));
+    HIP_TRY(hipEventElapsedTime(&ms3[0], cx->ev_start, cx->ev_stop));
     ms3[1] = 0.0f;
     ms3[2] = ms3[0];
-    if (g_ev_has_mid) {
-        HIP_TRY(hipEventElapsedTime(&ms3[1], g_ev_start, g_ev_mid));
-        HIP_TRY(hipEventElapsedTime(&ms3[2], g_ev_mid, g_ev_stop));
+    if (cx->ev_has_mid) {
+        HIP_TRY(hipEventElapsedTime(&ms3[1], cx->ev_start, cx->ev_mid));
+        HIP_TRY(hipEventElapsedTime(&ms3[2], cx->ev_mid, cx->ev_stop));
     }
     return CRT_OK;
 }
 
 float crt_last_kernel_ms(void) {
-    if (!g_ev_valid) { fail(CRT_ERR_INVALID, "crt_last_kernel_ms: no kernel launched on this thread"); return -1.0f; }
-    if (hipEventSynchronize(g_ev_stop) != hipSuccess) { fail(CRT_ERR_HIP, "crt_last_kernel_ms: event sync failed"); return -1.0f; }
-    float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, g_ev_start, g_ev_stop) != hipSuccess) { fail(CRT_ERR_HIP, "crt_last_kernel_ms: elapsed failed"); return -1.0f; }
-    return ms;
+    float ms3[3];
+    if (crt_last_kernel_times(ms3) != CRT_OK) return -1.0f;
+    return ms3[0];
 }
 
 int crt_render(int nx, int ny, int samples, int max_depth, int frame_index, const crt_scene* scene,

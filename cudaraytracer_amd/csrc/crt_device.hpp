@@ -110,15 +110,28 @@ constexpr int kLightChunks = 64;
 constexpr int kCtrLightCursor = 3 * kCtrLine;      // + k * kCtrLine: next position inside chunk k
 constexpr int kCtrWords = (3 + kLightChunks) * kCtrLine;
 
+// Occupancy of the persistent shading kernel, queried once per launch context and kernel.
+struct LaunchCache {
+    const void* fn = nullptr;
+    int resident = 0;
+};
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
-                         hipEvent_t ev_mid, hipStream_t stream);
+                         hipEvent_t ev_mid, LaunchCache* cache, hipStream_t stream);
+// Multi-GPU reassembly on rank 0 (dist: strips of `strip_rows` rows dealt round-robin to `world`
+// ranks): parts[r * part_stride ...] holds rank r's strips one after the other; every strip is
+// copied to its rows of the full nx x ny float3 frame.
+hipError_t launch_assemble_strips(const float* d_parts, long long part_stride, int nx, int ny, int strip_rows,
+                                  int world, float* d_full, hipStream_t stream);
 hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                         const uint32_t* d_state, const TiledWork* work, unsigned long long* d_counters,
                         hipStream_t stream);
 hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad,
                                    hipStream_t stream);
 constexpr int kStatsWords = 48;
+
+// Sets the calling thread's crt_last_error() text and returns `code` (host layer, crt_api.cpp).
+int set_error(int code, const char* fmt, ...);
 
 }  // namespace crt

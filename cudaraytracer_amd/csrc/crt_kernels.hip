@@ -934,8 +934,10 @@ static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int
     const int region_nx = (w.tiles_x + kRegionTilesX - 1) / kRegionTilesX, region_ny = (w.tiles_y + kRegionTilesY - 1) / kRegionTilesY;
     const int n_waves = (p.n_tris + kBinThreads - 1) / kBinThreads;
     int waves_min = kBinWavesMin, few = kFewTriangles;
-    if (const char* ev = getenv("CRT_BIN_FEW")) few = atoi(ev);   // tuning hook
-    if (const char* ev = getenv("CRT_BIN_WAVES")) waves_min = std::max(1, atoi(ev));   // tuning hook
+#ifdef CRT_TUNING   // tuning builds only (make tuning): the shipped library reads no environment
+    if (const char* ev = getenv("CRT_BIN_FEW")) few = std::max(0, atoi(ev));
+    if (const char* ev = getenv("CRT_BIN_WAVES")) waves_min = std::max(1, atoi(ev));
+#endif
     const int slices_y = std::max(1, std::min(region_ny, waves_min / std::max(n_waves, 1)));
     const int slices_x = std::max(1, std::min(region_nx, waves_min / std::max(n_waves * slices_y, 1)));
     const dim3 grid_tri((unsigned)n_waves, (unsigned)slices_y, (unsigned)slices_x);
@@ -1560,7 +1562,7 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const R
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
-                         hipEvent_t ev_mid, hipStream_t stream) {
+                         hipEvent_t ev_mid, LaunchCache* cache, hipStream_t stream) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     if (variant == 0 || d_cls == nullptr || work == nullptr) {
         dim3 block(256);
@@ -1578,15 +1580,19 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     const int tiles_per_cu = w.tiles_total / std::max(n_cus, 1);
     int dbg_repeat = 1, group = 8;
     int occ = (group == 8) ? 6 : 8;   // measured optimum with the LDS-staged light tiles
-    if (const char* e = getenv("CRT_SHADE_OCC")) occ = atoi(e);                  // tuning hooks (not part of the ABI)
+#ifdef CRT_TUNING   // tuning builds only (make tuning): the shipped library reads no environment
+    if (const char* e = getenv("CRT_SHADE_OCC")) occ = atoi(e);
     if (const char* e = getenv("CRT_SHADE_GROUP")) group = atoi(e);              // waves that share a heavy tile
-    if (const char* e = getenv("CRT_DEBUG_WALK_REPEAT")) dbg_repeat = atoi(e);   // timing experiments only
+    if (const char* e = getenv("CRT_DEBUG_WALK_REPEAT")) { dbg_repeat = atoi(e); if (dbg_repeat == 0) dbg_repeat = 1; }   // timing experiments only
+#endif
     // tiles with more survivors than this are shared by all waves of a block (measured: a full frame, and one
     // rank's strips of a 2-, 4-, 8-way split on the bench scene)
     int heavy = (variant == 2) ? 3 : (tiles_per_cu >= 96 ? kHeavyMin : (tiles_per_cu >= 24 ? kHeavyMinMedium : kHeavyMinSmall));
-    if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::min(atoi(e), 64);
     bool vrec = variant != 3;   // light tiles: records staged in LDS (VGPR operands); variant 3 keeps the scalar-operand walk (A/B)
+#ifdef CRT_TUNING
+    if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::max(1, std::min(atoi(e), 64));
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
+#endif
     using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int);
     ShadeFn fn;
     if (group == 8) {
@@ -1599,18 +1605,19 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         fn = vrec ? (occ == 4 ? shade_tiles_kernel<true, 4, 16> : shade_tiles_kernel<true, 8, 16>)
                   : (occ == 4 ? shade_tiles_kernel<false, 4, 16> : shade_tiles_kernel<false, 8, 16>);
     }
-    // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b)
-    static thread_local ShadeFn cached_fn = nullptr;
-    static thread_local int cached_resident = 0;
+    // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b);
+    // the occupancy query is cached per launch context (device + stream), not per host thread
     hipError_t e = hipSuccess;
-    if (cached_fn != fn) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&cached_resident, fn, group * 64, 0);
+    if (cache->fn != (const void*)fn) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&cache->resident, fn, group * 64, 0);
         if (e != hipSuccess) return e;
-        cached_fn = fn;
+        cache->fn = (const void*)fn;
     }
-    const int resident = cached_resident;
+    const int resident = cache->resident;
     int n_blocks = n_cus * std::max(resident, 1);
+#ifdef CRT_TUNING
     if (const char* ev = getenv("CRT_SHADE_GRID")) n_blocks = std::max(1, atoi(ev));
+#endif
     n_blocks = std::max(1, std::min(n_blocks, w.tiles_total));
     e = launch_binning(p, d_cls, n_pad, w, heavy, (unsigned)n_blocks, d_stats, stream);
     if (e != hipSuccess) return e;
@@ -1800,6 +1807,48 @@ hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, u
         hipLaunchKernelGGL(check_reciprocal_kernel, dim3(4096), dim3(256), 0, stream, exp_lo, exp_hi, d_bad);
     else
         hipLaunchKernelGGL(check_division_kernel, dim3(mode == 1 ? 32768 : 4096), dim3(256), 0, stream, mode, exp_lo, exp_hi, d_bad);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ multi-GPU reassembly
+// Rank 0 after the gather: rank r's piece (its 32-row strips one after the other) starts at
+// parts + r * part_stride; global strip s belongs to rank s % world and is that rank's strip
+// s / world (only the image's last strip can be short, so every earlier strip of a rank is full).
+// One element per thread, row-major over the destination: both sides are coalesced.  VEC: float4
+// when a row (nx * 3 floats) and every base offset are multiples of four floats.
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+assemble_strips_kernel(const float* __restrict__ parts, long long part_stride, int row_elems, int ny,
+                       int strip_rows, int world, float* __restrict__ full) {
+    const long long per_row = VEC ? row_elems / 4 : row_elems;
+    const long long total = per_row * ny;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / per_row);
+        const long long c = i - (long long)y * per_row;
+        const int s = y / strip_rows, r = s % world, k = s / world;
+        const long long src_row = (long long)k * strip_rows + (y - s * strip_rows);
+        if (VEC) {
+            const float4* src = reinterpret_cast<const float4*>(parts + (long long)r * part_stride + src_row * row_elems);
+            reinterpret_cast<float4*>(full + (long long)y * row_elems)[c] = src[c];
+        } else {
+            full[(long long)y * row_elems + c] = parts[(long long)r * part_stride + src_row * row_elems + c];
+        }
+    }
+}
+
+hipError_t launch_assemble_strips(const float* d_parts, long long part_stride, int nx, int ny, int strip_rows,
+                                  int world, float* d_full, hipStream_t stream) {
+    if (nx <= 0 || ny <= 0) return hipSuccess;
+    const int row_elems = nx * 3;
+    const bool vec = row_elems % 4 == 0 && part_stride % 4 == 0 && ((uintptr_t)d_parts & 15u) == 0 && ((uintptr_t)d_full & 15u) == 0;
+    const long long total = (long long)(vec ? row_elems / 4 : row_elems) * ny;
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
+    if (vec)
+        hipLaunchKernelGGL(assemble_strips_kernel<true>, dim3(blocks), dim3(256), 0, stream, d_parts, part_stride, row_elems, ny,
+                           strip_rows, world, d_full);
+    else
+        hipLaunchKernelGGL(assemble_strips_kernel<false>, dim3(blocks), dim3(256), 0, stream, d_parts, part_stride, row_elems, ny,
+                           strip_rows, world, d_full);
     return hipGetLastError();
 }
 

@@ -95,6 +95,11 @@ def gather_strips(piece, nx, ny, rank, world_size, strip_rows=STRIP_ROWS, group=
     if parts is None:
         return None
     full = parts.new_empty(ny, nx, 3)
+    if parts.is_cuda:      # the root's reassembly kernel (crt_assemble_strips) on the current stream
+        from . import api
+        api.assemble_strips(parts, parts.stride(0), nx, ny, strip_rows, world_size, full,
+                            stream=torch.cuda.current_stream())
+        return full
     strip_elems = strip_rows * nx * 3
     rounds = ny // (strip_rows * world_size)               # rounds in which every rank has a full strip
     if rounds > 0:
@@ -126,7 +131,7 @@ class BandRenderer:
                 if self.row_count else None
         else:
             self.row_begin, self.row_count = partition_rows(ny, world_size, rank)
-            self.state = api.SetCurandState(nx, ny, seed, self.row_begin, self.row_count)
+            self.state = api.SetCurandState(nx, ny, seed, self.row_begin, self.row_count) if self.row_count else None
         # the piece is rendered straight into the padded send buffer of the gather
         if self.mode == "strips":
             max_rows = max(sum(c for _, c in partition_strips(ny, world_size, r)) for r in range(world_size))

@@ -108,6 +108,34 @@ def dragon1m():
     return displaced_sphere(500, 1000)
 
 
+# ---- the BASELINE.json frames, ONE definition for bench.py and the tests -------------------
+# name -> (nx, ny, spp, n_lat, n_lon): the mesh is written as an OBJ file (1-based `f a b c`
+# records) and read back through the OBJ loader (mean centring, Loader/obj_loader.h:120-133),
+# scale 1, reference camera (createScene.h:160) — exactly what bench.py times.
+BASELINE_FRAMES = {
+    "C3": (1920, 1080, 64, 200, 250),      # configs[2]: 100 000 triangles, 1 GPU
+    "C4": (1920, 1080, 256, 200, 250),     # configs[3]: same mesh, 256 spp, 8-way split
+    "C5": (3840, 2160, 64, 500, 1000),     # configs[4]: 1 000 000 triangles
+}
+
+
+def baseline_mesh(name):
+    """The mesh of a BASELINE frame before the OBJ round trip (index_base 1)."""
+    n_lat, n_lon = BASELINE_FRAMES[name][3:5]
+    return displaced_sphere(n_lat, n_lon, radius=200.0, centre=(0.0, 0.0, 0.0), index_base=1)
+
+
+def baseline_obj(name, folder):
+    """Write the frame's OBJ file into `folder` (once) and return (path, nx, ny, spp)."""
+    import os
+    nx, ny, spp = BASELINE_FRAMES[name][:3]
+    n_lat, n_lon = BASELINE_FRAMES[name][3:5]
+    path = os.path.join(folder, "synthetic_%dx%d.obj" % (n_lat, n_lon))
+    if not os.path.exists(path):
+        write_obj(path, baseline_mesh(name))
+    return path, nx, ny, spp
+
+
 def random_soup(n_tris, seed, extent=4.0, size=1.5, z_range=(-12.0, 6.0)):
     """Adversarial triangle soup around a camera at the origin looking down -z: triangles in
     front of AND behind the camera (the reference accepts negative t), random stored
@@ -135,10 +163,10 @@ def write_obj(path, scene):
     Loader/obj_loader.h:44-64); indices are written 1-based."""
     pts, idx = scene["points"], scene["idx"]
     off = 1 - scene["index_base"]
-    with open(path, "w") as f:
+    tmp = path + ".tmp%d" % __import__("os").getpid()
+    with open(tmp, "w") as f:
         f.write("# synthetic mesh: %d vertices, %d faces\n" % (len(pts), len(idx)))
-        for p in pts:
-            f.write("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
-        for t in idx.astype(np.int64) + off:
-            f.write("f %d %d %d\n" % (t[0], t[1], t[2]))
+        f.write("".join(["v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]) for p in pts.astype(np.float64).tolist()]))
+        f.write("".join(["f %d %d %d\n" % (t[0], t[1], t[2]) for t in (idx.astype(np.int64) + off).tolist()]))
+    __import__("os").replace(tmp, path)
     return path

@@ -13,8 +13,21 @@
  *     checkCudaErrors / CHECK, core/deviceManage.h:3-17); crt_last_error() gives the text
  *   - the library owns device memory behind opaque handles; the caller owns every buffer
  *     it passes in (host or device)
- *   - thread-compatible: one handle set per host thread; every call works on the HIP
- *     device that is current when the handle was created
+ *   - devices: a handle (scene, RNG states) lives on the HIP device that was current when it
+ *     was created; every call that uses it must be made with that device current, otherwise
+ *     CRT_ERR_INVALID.
+ *   - streams and threads: render entry points only ENQUEUE work on the stream they are given.
+ *     Everything a launch writes besides its outputs (per-frame derived triangle records,
+ *     binning scratch, timing events) belongs to a launch context keyed by (device, stream),
+ *     so renders on different streams or devices — same scene or not, same host thread or not
+ *     — are independent; renders on one stream are ordered by the stream.  One crt_rng must not
+ *     be in flight on two streams at once (its states are advanced in place), and
+ *     crt_scene_update_pose must be ordered by the caller against renders of that scene on
+ *     OTHER streams (same stream: ordered by the stream).  crt_last_error, crt_last_kernel_*,
+ *     crt_set_kernel_variant and crt_debug_tiled_stats are per calling thread.
+ *   - "bit-exact" in this file means: identical to the in-repo CPU oracle (oracle/), which is
+ *     a restatement of the reference and is PARITY UNPINNED (no reference fixtures exist and
+ *     the reference cannot be built here; see oracle/crt_oracle.h).
  *   - there is NO CPU fallback: every compute entry point fails with CRT_ERR_NO_DEVICE
  *     when no HIP device is usable
  */
@@ -27,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 1
+#define CRT_ABI_VERSION 2
 
 enum {
     CRT_OK = 0,
@@ -90,19 +103,25 @@ crt_scene *crt_scene_from_mesh(const float *points, int n_points, const float *i
  * every triangle are re-read from `new_points` (n_points x 3 floats, host; n_points must equal the
  * count the scene was built from) through the scene's index triplets in the same reversed winding;
  * stored normals are kept (Triangle::SetVertices, shapes/triangle.h:40-45).  Enqueued on `stream`
- * (hipStream_t, NULL = default); the next crt_render_rows on that stream sees the new pose. */
+ * (hipStream_t, NULL = default); the next crt_render_rows on that stream sees the new pose.
+ * `new_points` is copied into a pinned staging buffer before the call returns: the caller may
+ * reuse it at once. */
 int crt_scene_update_pose(crt_scene *scene, const float *new_points, int n_points, void *stream);
 
 /* replaces: parseObjByName (Loader/obj_loader.h:20-111) + computeMean/centering
  * (:120-133) + the historic `points[i] *= 100.0` scale (:164) + the scene pack above with
- * index_base 1 and computed normals.  Only `v x y z` and `f a b c` records are read, as
- * in the reference. */
+ * index_base 1 and computed normals.  `v x y z` and `f a b c` records are read as in the
+ * reference.  Deliberate extension beyond it (the reference's `ss >> float`
+ * stops at the first '/'): face tokens `a/b`, `a//c`, `a/b/c` use their leading vertex index,
+ * negative indices count back from the latest vertex, polygons are fanned into triangles
+ * (v0, vk, vk+1) — this is what makes CudaTest/objects/cbox_smallbox.obj loadable. */
 crt_scene *crt_scene_from_obj(const char *path, float scale, const float albedo[3]);
 
 int crt_scene_triangle_count(const crt_scene *scene);
 void crt_scene_free(crt_scene *scene);
 
-/* Host-side OBJ parse only (same rules as crt_scene_from_obj, before scaling): call with
+/* Host-side OBJ parse only (same rules as crt_scene_from_obj, before scaling; n_tris counts the
+ * triangles after fanning): call with
  * NULL buffers to get the counts, then with buffers of n_points*3 / n_tris*3 floats. */
 int crt_parse_obj(const char *path, float *points, float *idx3f, int *n_points, int *n_tris);
 
@@ -226,6 +245,54 @@ float crt_last_kernel_ms(void);
  * brute-force variant), ms3[2] = shading / brute-force kernel. */
 int crt_last_kernel_times(float *ms3);
 
+/* ---- multi-GPU ------------------------------------------------------------------
+ * The reference is single-GPU; this section is the north-star split: strips of
+ * `strip_rows` (32) image rows dealt round-robin to `world` ranks, rendered with
+ * crt_render_strips, then ONE exchange step — a grouped RCCL send/recv of the float3 pieces to
+ * rank 0 (rccl.h ncclSend/ncclRecv in ncclGroupStart/End) — and a reassembly kernel there. */
+
+/* Floats between the pieces of consecutive ranks in the root's receive buffer: the largest
+ * piece (rank 0's) rounded up to 4 floats.  The buffer holds world * stride floats. */
+int64_t crt_strip_part_stride(int nx, int ny, int strip_rows, int world);
+
+/* Reassembly on the root (HIP kernel on `stream`): d_parts + r * part_stride holds rank r's
+ * strips one after the other (layout of crt_render_strips); d_full receives the nx x ny float3
+ * frame, row 0 = bottom.  Both are device pointers on the current device. */
+int crt_assemble_strips(const float *d_parts, int64_t part_stride, int nx, int ny, int strip_rows,
+                        int world, float *d_full, void *stream);
+
+/* One process (or thread) per GPU: every rank calls this after crt_render_strips with the same
+ * layout, its own rank, its ncclComm_t (`nccl_comm`, created by the caller with
+ * ncclCommInitRank / ncclCommInitAll) and the stream the piece was rendered on.  Rank 0 also
+ * passes the receive buffer (world * part_stride floats) and d_full (nx*ny*3 floats); other
+ * ranks pass NULL for both.  Enqueues: ncclGroupStart; ncclSend(piece -> 0) on every rank,
+ * the root included; on rank 0 one ncclRecv per rank; ncclGroupEnd; then on rank 0 the
+ * reassembly kernel.  RCCL is bound at first use (dlopen librccl.so.1): CRT_ERR_UNSUPPORTED if
+ * it cannot be loaded. */
+int crt_gather_strips(const float *d_piece, int nx, int ny, int strip_rows, int rank, int world,
+                      float *d_parts, int64_t part_stride, float *d_full, void *nccl_comm,
+                      void *stream);
+
+/* One process, n_gpus devices (devices 0..n_gpus-1): the scene is replicated, every device gets
+ * its strip set's RNG states (seed, stream = global pixel index), a stream and a host worker
+ * thread; communicators come from ncclCommInitAll.  replaces: the driver shape of
+ * renderListAnimation (core/render.h:159-189) for n_gpus devices. */
+typedef struct crt_multi crt_multi;
+crt_multi *crt_multi_create(const float *points, int n_points, const float *idx3f, int n_tris,
+                            const float *face_normals, int index_base, const float albedo[3],
+                            int nx, int ny, uint64_t seed, int n_gpus);
+/* One frame: every device renders its strips, one grouped send/recv, reassembly on device 0,
+ * and (rgb_out != NULL) a copy of the nx*ny*3 floats to the host.  Synchronous.  The RNG
+ * states persist from call to call like the reference's frame loop. */
+int crt_multi_render(crt_multi *m, const crt_camera *camera, int samples, int max_depth,
+                     int frame_index, float *rgb_out);
+/* crt_scene_update_pose on every replica. */
+int crt_multi_update_pose(crt_multi *m, const float *new_points, int n_points);
+/* Device pointer (device 0) of the frame assembled by the last crt_multi_render. */
+const float *crt_multi_frame(const crt_multi *m);
+int crt_multi_device_count(const crt_multi *m);
+void crt_multi_free(crt_multi *m);
+
 /* ---- output -------------------------------------------------------------------- */
 
 /* replaces: WritePng's conversion loop (core/render.h:137-146): vertical flip,
@@ -236,6 +303,8 @@ void crt_to_rgba8(const float *rgb, int nx, int ny, unsigned char *rgba);
  * `path` (the reference calls stbi_write_png(path, nx, ny, 4, rgb, 0), :153; this library
  * carries its own zlib-based PNG encoder — same pixels, not the same compressed bytes). */
 int crt_write_png(const char *path, int nx, int ny, const float *rgb);
+/* The encoder alone: rgba is nx*ny*4 bytes, top row first (what crt_to_rgba8 produces). */
+int crt_write_png_rgba8(const char *path, int nx, int ny, const unsigned char *rgba);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(crt_built):
         assert hasattr(crt_built, n), "libcrt_hip.so does not export %s" % n
         assert n in _lib.PROTOTYPES, "no ctypes prototype for %s" % n
     assert set(_lib.PROTOTYPES) == set(names)
-    assert crt_built.crt_abi_version() == 1
+    assert crt_built.crt_abi_version() == 2
 
 
 def test_camera_matches_oracle(crt_built, oracle):
@@ -58,6 +58,45 @@ def test_parse_obj_matches_oracle(crt_built, oracle, tmp_path):
     assert i.tolist() == [[1, 2, 3], [1, 3, 2]] and p.shape == (3, 3)
     with pytest.raises(_lib.CrtError):
         api.parse_obj(str(tmp_path / "missing.obj"))
+
+
+def test_parse_obj_quads_negative_indices_and_the_reference_cbox(crt_built, tmp_path):
+    """Beyond the reference's reader: polygons are fanned, negative indices
+    count back from the latest vertex, `a//n` tokens use their leading index — the format of
+    the reference-held CudaTest/objects/cbox_smallbox.obj (reproduced here in its first two
+    faces; the file itself is not available on the GPU box)."""
+    with open(str(tmp_path / "q.obj"), "w") as f:
+        f.write("v 0 0 0\nv 2 0 0\nv 2 2 0\nv 0 2 0\nf 1 2 3 4\n"         # quad -> (1,2,3), (1,3,4)
+                "v 0 0 1\nf -1 -5 -4\n"                                       # relative: 5, 1, 2
+                "f 1/9 2/9 3/9 4/9 5/9\n")                                    # pentagon -> 3 triangles
+    p, i = api.parse_obj(str(tmp_path / "q.obj"))
+    assert p.shape == (5, 3)
+    assert i.tolist() == [[1, 2, 3], [1, 3, 4], [5, 1, 2], [1, 2, 3], [1, 3, 4], [1, 4, 5]]
+    mean = np.array([[0, 0, 0], [2, 0, 0], [2, 2, 0], [0, 2, 0], [0, 0, 1]], dtype=np.float32).sum(axis=0) / np.float32(5)
+    assert np.allclose(p[0], -mean)
+    with open(str(tmp_path / "cbox.obj"), "w") as f:                          # Meshlab style, as in cbox_smallbox.obj:12-45
+        f.write("vn 0.000000 1.000000 0.000000\nv 130.000000 165.000000 65.000000\nv 82.000000 165.000000 225.000000\n"
+                "v 240.000000 165.000000 272.000000\nv 290.000000 165.000000 114.000000\n"
+                "f 1//1 2//1 3//1\nf 1//1 3//1 4//1\n")
+    p, i = api.parse_obj(str(tmp_path / "cbox.obj"))
+    assert p.shape == (4, 3) and i.tolist() == [[1, 2, 3], [1, 3, 4]]
+    ref = "/root/reference/CudaTest/objects/cbox_smallbox.obj"
+    if os.path.exists(ref):                                                    # build container only
+        p, i = api.parse_obj(ref)
+        assert p.shape == (24, 3) and i.shape == (12, 3) and i.min() == 1 and i.max() == 24
+
+
+def test_strip_part_stride_and_layout_checks(crt_built):
+    L = crt_built
+    for nx, ny, world in [(1920, 1080, 8), (3840, 2160, 8), (90, 150, 3), (7, 33, 2), (5, 40, 1)]:
+        rows0 = L.crt_strip_rows(ny, 0, 32, world)
+        stride = L.crt_strip_part_stride(nx, ny, 32, world)
+        assert stride % 4 == 0 and rows0 * nx * 3 <= stride < rows0 * nx * 3 + 4
+        for r in range(1, world):
+            if r * 32 < ny:
+                assert L.crt_strip_rows(ny, r, 32, world) <= rows0
+    assert L.crt_strip_part_stride(0, 10, 32, 2) == _lib.CRT_ERR_INVALID
+    assert L.crt_strip_part_stride(10, 10, 24, 2) == _lib.CRT_ERR_INVALID      # strips of a split are multiples of 32 rows
 
 
 def decode_png(path):
@@ -105,6 +144,7 @@ def test_compute_entry_points_fail_loudly_without_device(crt_built):
     if crt_built.crt_device_count() > 0:
         pytest.skip("a HIP device is present")
     L = crt_built
+    pts9 = np.zeros(9, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
     assert not L.crt_rng_create(0, 16, 0)
     assert b"no HIP device" in L.crt_last_error()
     sc = scenes.quad()
@@ -117,6 +157,14 @@ def test_compute_entry_points_fail_loudly_without_device(crt_built):
     assert rc == _lib.CRT_ERR_NO_DEVICE
     with pytest.raises(_lib.CrtError):
         api.renderListAnimation(2, 2, 1, 8, 0, 0, None, cam, None)
+    assert L.crt_assemble_strips(C.c_void_p(16), 4096, 8, 8, 32, 1, C.c_void_p(16), None) == _lib.CRT_ERR_NO_DEVICE
+    assert L.crt_gather_strips(C.c_void_p(16), 8, 8, 32, 0, 1, C.c_void_p(16), 4096, C.c_void_p(16), C.c_void_p(16), None) \
+        == _lib.CRT_ERR_NO_DEVICE
+    assert L.crt_gather_strips(C.c_void_p(16), 8, 8, 32, 0, 1, C.c_void_p(16), 4096, C.c_void_p(16), None, None) \
+        == _lib.CRT_ERR_INVALID                                                 # no communicator
+    a3 = (C.c_float * 3)(0.5, 0.5, 0.5)
+    assert not L.crt_multi_create(pts9, 3, pts9, 1, None, 0, a3, 8, 8, 0, 1)
+    assert b"no HIP device" in L.crt_last_error()
     pts = np.zeros(9, dtype=np.float32)
     assert L.crt_scene_update_pose(None, pts.ctypes.data_as(C.POINTER(C.c_float)), 3, None) == _lib.CRT_ERR_INVALID
 

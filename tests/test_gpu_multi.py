@@ -1,0 +1,151 @@
+"""GPU tests of the multi-GPU half of the C ABI on ONE device (the GPU box has one):
+launch contexts per (device, stream), the root's reassembly kernel, the grouped RCCL send/recv
+of crt_gather_strips (world 1: the root sends to itself through RCCL) and the single-process
+driver crt_multi_* (ncclCommInitAll over one device).  The frame of every path must equal the
+single-launch frame bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cudaraytracer_amd import _lib, api, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(crt_built):
+    if crt_built.crt_device_count() < 1:
+        pytest.fail("no HIP device visible: the product has no CPU fallback")
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def make(sc, nx, ny):
+    scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    c = sc["camera"]
+    return scene, api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+
+
+def full_frame(gpu, scene, cam, nx, ny, spp):
+    st = api.SetCurandState(nx, ny, 0)
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=gpu.cuda.current_stream())
+    gpu.cuda.synchronize()
+    return d.cpu().numpy().reshape(ny, nx, 3)
+
+
+def test_two_streams_one_thread_one_scene(gpu):
+    """Two bands of one scene enqueued back to back on two streams from one host thread (and a
+    second camera on a third): every launch has its own context (derived records, binning
+    scratch), so the bands equal the single-launch frame."""
+    sc = scenes.displaced_sphere(60, 80)
+    nx, ny, spp = 640, 384, 8
+    scene, cam = make(sc, nx, ny)
+    want = full_frame(gpu, scene, cam, nx, ny, spp)
+    cam2 = api.create_camera(nx, ny, (300.0, 400.0, 900.0), (0.0, 150.0, 0.0), 10.0, 0.0, 35.0)
+    want2 = full_frame(gpu, scene, cam2, nx, ny, spp)
+    s1, s2, s3 = gpu.cuda.Stream(), gpu.cuda.Stream(), gpu.cuda.Stream()
+    half = ny // 2
+    for _ in range(3):                                   # repeated: a race would not show every time
+        st_a = api.SetCurandState(nx, ny, 0, 0, half)
+        st_b = api.SetCurandState(nx, ny, 0, half, ny - half)
+        st_c = api.SetCurandState(nx, ny, 0)
+        a = gpu.zeros(half * nx * 3, dtype=gpu.float32, device="cuda")
+        b = gpu.zeros((ny - half) * nx * 3, dtype=gpu.float32, device="cuda")
+        c = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+        gpu.cuda.synchronize()
+        api.render_rows(scene, cam, st_a, nx, ny, spp, 0, half, a, stream=s1)
+        api.render_rows(scene, cam2, st_c, nx, ny, spp, 0, ny, c, stream=s3)
+        api.render_rows(scene, cam, st_b, nx, ny, spp, half, ny - half, b, stream=s2)
+        gpu.cuda.synchronize()
+        got = np.concatenate([a.cpu().numpy().reshape(half, nx, 3), b.cpu().numpy().reshape(ny - half, nx, 3)], axis=0)
+        assert np.array_equal(bits(got), bits(want))
+        assert np.array_equal(bits(c.cpu().numpy().reshape(ny, nx, 3)), bits(want2))
+
+
+@pytest.mark.parametrize("nx,ny,world", [(640, 360, 8), (90, 150, 3), (33, 70, 2), (1920, 1080, 8)])
+def test_assemble_strips_kernel(gpu, crt_built, nx, ny, world):
+    """Every rank's strip set rendered on this GPU into the root's receive layout
+    (rank r at r * part_stride), then crt_assemble_strips == the single-launch frame."""
+    sc = scenes.displaced_sphere(24, 30)
+    spp = 2
+    scene, cam = make(sc, nx, ny)
+    want = full_frame(gpu, scene, cam, nx, ny, spp)
+    stride = api.strip_part_stride(nx, ny, 32, world)
+    parts = gpu.full((world * stride,), float("nan"), dtype=gpu.float32, device="cuda")
+    for r in range(world):
+        if r * 32 >= ny:
+            continue
+        st = api.CurandState.for_strips(nx, ny, r, 32, world, 0)
+        api.render_strips(scene, cam, st, nx, ny, spp, r, 32, world, parts.data_ptr() + 4 * r * stride,
+                          stream=gpu.cuda.current_stream())
+    full = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    api.assemble_strips(parts, stride, nx, ny, 32, world, full, stream=gpu.cuda.current_stream())
+    gpu.cuda.synchronize()
+    assert np.array_equal(bits(full.cpu().numpy().reshape(ny, nx, 3)), bits(want))
+
+
+def _rccl():
+    """The RCCL copy this process holds (torch's), through ctypes: ncclCommInitAll over device 0."""
+    lib = C.CDLL("librccl.so.1")
+    lib.ncclCommInitAll.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+    lib.ncclCommDestroy.argtypes = [C.c_void_p]
+    return lib
+
+
+def test_gather_strips_through_rccl_world_one(gpu):
+    """crt_gather_strips with a real ncclComm_t: at world 1 the root's send to itself and its
+    receive go through RCCL's grouped send/recv, then the reassembly kernel runs."""
+    sc = scenes.displaced_sphere(24, 30)
+    nx, ny, spp = 200, 120, 2
+    scene, cam = make(sc, nx, ny)
+    want = full_frame(gpu, scene, cam, nx, ny, spp)
+    rccl = _rccl()
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(gpu.cuda.current_device())
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        st = api.CurandState.for_strips(nx, ny, 0, 32, 1, 0)
+        piece = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+        stride = api.strip_part_stride(nx, ny, 32, 1)
+        parts = gpu.zeros(stride, dtype=gpu.float32, device="cuda")
+        full = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+        stream = gpu.cuda.Stream()
+        gpu.cuda.synchronize()
+        api.render_strips(scene, cam, st, nx, ny, spp, 0, 32, 1, piece, stream=stream)
+        api.gather_strips(piece, nx, ny, 32, 0, 1, parts, stride, full, comm.value, stream=stream)
+        stream.synchronize()
+        assert np.array_equal(bits(full.cpu().numpy().reshape(ny, nx, 3)), bits(want))
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
+def test_single_process_driver_on_one_device(gpu, oracle):
+    """crt_multi_* with n_gpus = 1 (ncclCommInitAll, stream + host worker per device): two frames
+    continue the RNG streams like the reference's frame loop; a pose update reaches the replica."""
+    sc = scenes.displaced_sphere(16, 20)
+    nx, ny, spp = 96, 80, 3
+    m = api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 1)
+    c = sc["camera"]
+    cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+    f0 = m.render(cam, spp)
+    moved = (sc["points"] * np.float32(1.1)).astype(np.float32)
+    m.update_pose(moved)
+    f1 = m.render(cam, spp, frame_index=1)
+    m.close()
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    ocam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny),
+                              c["aperture"], c["focus"])
+    r0, states = oracle.render(w, ocam, nx, ny, spp)
+    assert np.array_equal(bits(f0), bits(r0))
+    w.update_pose(moved)
+    r1, _ = oracle.render(w, ocam, nx, ny, spp, states=states, frame=1)
+    assert np.array_equal(bits(f1).reshape(-1, 3)[1:], bits(r1).reshape(-1, 3)[1:])   # pixel 0 of frame 1: DESIGN.md §1
+    with pytest.raises(_lib.CrtError):
+        api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 99)

@@ -78,5 +78,36 @@ def main():
         print(name, buf.shape, "hit-rays %d/%d" % (int(sum(h[0] for h in hits)), len(hits)))
 
 
+def small_bunny():
+    """SURVEY §8c golden (4): the only real mesh the reference ships for this path,
+    CudaTest/objects/small_bunny.obj (2503 v / 4968 f, plain `f a b c`), read by the oracle's
+    restatement of parseObjByName (mean-centred), scaled x100 like the historic BuildObjMesh
+    (Loader/obj_loader.h:164), 64x64x4 spp.  The fixture holds the mesh arrays (data, so the
+    GPU box needs no /root/reference) and the oracle's frame.  The historic camera
+    (create_camera_origin) no longer exists in the reference; this one looks at the bunny from
+    (0, 5, 35)."""
+    ref = "/root/reference/CudaTest/objects/small_bunny.obj"
+    if not os.path.exists(ref):
+        print("small_bunny: reference mesh not available here, fixture left as is")
+        return
+    pts, idx = po.parse_obj(ref)
+    assert pts.shape == (2503, 3) and idx.shape == (4968, 3)
+    pts = (pts * np.float32(100.0)).astype(np.float32)
+    nx = ny = 64
+    spp = 4
+    w = po.World(pts, idx, None, 1)
+    look = dict(lookfrom=(0.0, 5.0, 35.0), lookat=(0.0, 0.0, 0.0), vfov=40.0, aperture=0.0, focus=10.0)
+    cam = po.make_camera(look["lookfrom"], look["lookat"], (0, 1, 0), look["vfov"], np.float32(nx) / np.float32(ny), 0.0, 10.0)
+    buf, states = po.render(w, cam, nx, ny, spp)
+    after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+    np.savez_compressed(os.path.join(OUT, "small_bunny_64x64x4.npz"), rgb=buf, points=pts, idx=idx,
+                        camera=po.camera_as_array(cam), lookfrom=np.array(look["lookfrom"], dtype=np.float32),
+                        lookat=np.array(look["lookat"], dtype=np.float32), states_after=after,
+                        rgba=po.to_rgba8(buf), nx=nx, ny=ny, spp=spp)
+    hit = (buf[..., 0] - buf[..., 2]) > 0.05
+    print("small_bunny", buf.shape, "hit pixels %d / %d" % (int(hit.sum()), nx * ny))
+
+
 if __name__ == "__main__":
+    small_bunny()
     main()
