@@ -310,7 +310,7 @@ static o_ray TransformRay(const o_transform *tr, const o_ray *r) {        /* tra
 
 /* ------------------------------------------------------------------ hitable/hitable.h */
 
-typedef struct { float t, u, v; o_vec3 p, normal; int mat_set; } o_hitrec; /* hitable.h:11-18 */
+typedef struct { float t, u, v; o_vec3 p, normal; int mat_set; int tri; } o_hitrec; /* hitable.h:11-18; tri = index of the triangle mat_ptr belongs to */
 
 /* shapes/triangle.h:57-100 */
 static int triangle_collision_detection(const o_triangle *tri, const o_ray *r, float t_min, float t_max, o_hitrec *rec) {
@@ -367,6 +367,7 @@ static int list_collision_detection(const o_world *w, const o_ray *r, float t_mi
             hit_anything = 1;
             closest_so_far = tmp_rec.t;
             *rec = tmp_rec;
+            rec->tri = i;
             if (index) *index = i;
         }
     }
@@ -387,6 +388,294 @@ int o_world_hit(const o_world *world, const float origin[3], const float directi
     memset(&rec, 0, sizeof rec);
     int idx = -1;
     int flag = world_hit(world, &r, 0.001f, FLT_MAX, &rec, &idx);
+    if (t_out) *t_out = rec.t;
+    if (index_out) *index_out = flag ? idx : -1;
+    if (normal_out) { normal_out[0] = rec.normal.e[0]; normal_out[1] = rec.normal.e[1]; normal_out[2] = rec.normal.e[2]; }
+    return flag;
+}
+
+/* ------------------------------------------------------------------ core/aabb.h */
+
+static float ffmin(float a, float b) { return a < b ? a : b; }           /* aabb.h:7 */
+static float ffmax(float a, float b) { return a > b ? a : b; }           /* aabb.h:8 */
+
+static int aabb_hit(const o_aabb *box, const o_ray *r, float t_min, float t_max) { /* aabb.h:30-43 */
+    for (int a = 0; a < 3; a++) {
+        float t0 = ffmin((box->_min.e[a] - r->_origin.e[a]) / r->_direction.e[a],
+                         (box->_max.e[a] - r->_origin.e[a]) / r->_direction.e[a]);
+        float t1 = ffmax((box->_min.e[a] - r->_origin.e[a]) / r->_direction.e[a],
+                         (box->_max.e[a] - r->_origin.e[a]) / r->_direction.e[a]);
+        t_min = ffmax(t0, t_min);
+        t_max = ffmin(t1, t_max);
+        if (t_max <= t_min) return 0;
+    }
+    return 1;
+}
+
+static o_aabb surrounding_box(o_aabb box0, o_aabb box1) {                 /* aabb.h:58-66: fmin/fmax */
+    o_aabb r;
+    r._min = v3(fminf(box0._min.e[0], box1._min.e[0]), fminf(box0._min.e[1], box1._min.e[1]), fminf(box0._min.e[2], box1._min.e[2]));
+    r._max = v3(fmaxf(box0._max.e[0], box1._max.e[0]), fmaxf(box0._max.e[1], box1._max.e[1]), fmaxf(box0._max.e[2], box1._max.e[2]));
+    return r;
+}
+
+static void TransformAABB(const o_transform *tr, o_aabb *aabb) {          /* transform.h:22-31 */
+    o_vec3 rotetedMin = rotate(aabb->_min, tr->rotation);
+    o_vec3 rotetedMax = rotate(aabb->_max, tr->rotation);
+    /* minVec3 / maxVec3, vec3.h:233-239: CUDA's min/max(float,float) = fminf/fmaxf */
+    o_vec3 mn = v3(fminf(rotetedMin.e[0], rotetedMax.e[0]), fminf(rotetedMin.e[1], rotetedMax.e[1]), fminf(rotetedMin.e[2], rotetedMax.e[2]));
+    o_vec3 mx = v3(fmaxf(rotetedMin.e[0], rotetedMax.e[0]), fmaxf(rotetedMin.e[1], rotetedMax.e[1]), fmaxf(rotetedMin.e[2], rotetedMax.e[2]));
+    aabb->_min = add(mn, tr->position);
+    aabb->_max = add(mx, tr->position);
+}
+
+static void triangle_bounding_box(const o_triangle *t, o_aabb *bbox) {    /* triangle.h:102-115 (min/max = fminf/fmaxf) */
+    float minX = fminf(t->vertices[0].e[0], fminf(t->vertices[1].e[0], t->vertices[2].e[0]));
+    float minY = fminf(t->vertices[0].e[1], fminf(t->vertices[1].e[1], t->vertices[2].e[1]));
+    float minZ = fminf(t->vertices[0].e[2], fminf(t->vertices[1].e[2], t->vertices[2].e[2]));
+    float maxX = fmaxf(t->vertices[0].e[0], fmaxf(t->vertices[1].e[0], t->vertices[2].e[0]));
+    float maxY = fmaxf(t->vertices[0].e[1], fmaxf(t->vertices[1].e[1], t->vertices[2].e[1]));
+    float maxZ = fmaxf(t->vertices[0].e[2], fmaxf(t->vertices[1].e[2], t->vertices[2].e[2]));
+    bbox->_min = v3(minX, minY, minZ);
+    bbox->_max = v3(maxX, maxY, maxZ);
+}
+
+static void triangle_GetBV(const o_triangle *t, o_aabb *box) {            /* hitable.h:45-50 */
+    triangle_bounding_box(t, box);
+    TransformAABB(&t->transform, box);
+}
+
+/* ------------------------------------------------------------------ hitable/bvh.h
+ * BVHNode (bvh.h:48-190) over the triangles of a HitableList.  The reference sorts the list's
+ * Hitable* array in place with thrust::sort inside ONE device thread (bvh.h:86-92) and a
+ * comparator that is not a strict weak ordering (BoxCompare returns true when the keys are
+ * equal, bvh.h:36-41), so the resulting order is whatever the algorithm does with it.
+ * PARITY UNPINNED at this boundary — the rule adopted here: Thrust's sequential backend
+ * (what thrust::sort resolves to inside a device thread), i.e. the iterative stable merge
+ * sort of thrust/system/detail/sequential/stable_merge_sort.inl — insertion sort of every
+ * 32-element partition (insertion_sort.h), then merges of adjacent partitions ping-ponging
+ * with a temporary array (merge.inl) — restated below with the comparator fed literally. */
+
+struct o_bvh {
+    o_world *world;        /* the list whose triangles the leaves point at (not owned) */
+    int *order;            /* the list's Hitable* array after all in-place sorts: order[slot] = triangle index */
+    o_bvh_node *nodes;     /* preorder; nodes[0] is the root */
+    int n_nodes, cap;
+};
+
+static int box_compare(const float *key, int a, int b) {                  /* BoxCompare::operator(), bvh.h:11-41 */
+    float val1 = key[a], val2 = key[b];
+    if (val1 - val2 < 0.0) return 0;
+    else return 1;
+}
+
+static void thrust_insertion_sort(int *first, int *last, const float *key) { /* sequential/insertion_sort.h */
+    if (first == last) return;
+    for (int *i = first + 1; i != last; ++i) {
+        int tmp = *i;
+        if (box_compare(key, tmp, *first)) {
+            memmove(first + 1, first, (size_t)(i - first) * sizeof(int)); /* copy_backward(first, i, i + 1) */
+            *first = tmp;
+        } else {
+            int *j = i, *k = i - 1;
+            while (box_compare(key, tmp, *k)) { *j = *k; j = k; --k; }
+            *j = tmp;
+        }
+    }
+}
+
+static void thrust_merge(const int *first1, const int *last1, const int *first2, const int *last2, int *result, const float *key) { /* sequential/merge.inl */
+    while (first1 != last1 && first2 != last2) {
+        if (box_compare(key, *first2, *first1)) { *result = *first2; ++first2; }
+        else { *result = *first1; ++first1; }
+        ++result;
+    }
+    while (first1 != last1) *result++ = *first1++;
+    while (first2 != last2) *result++ = *first2++;
+}
+
+static void thrust_seq_sort(int *first, int n, const float *key, int *temp) { /* iterative_stable_merge_sort */
+    int partition_size = 32;
+    for (int at = 0; at < n; at += partition_size)                           /* insertion_sort_each */
+        thrust_insertion_sort(first + at, first + (at + partition_size < n ? at + partition_size : n), key);
+    if (n <= partition_size) return;
+    int ping = 1;
+    for (; partition_size < n; partition_size *= 2, ping = !ping) {          /* merge_adjacent_partitions */
+        const int *src = ping ? first : temp;
+        int *dst = ping ? temp : first;
+        for (int at = 0; at < n; at += 2 * partition_size) {
+            int mid = at + partition_size < n ? at + partition_size : n;
+            int end = mid + partition_size < n ? mid + partition_size : n;
+            thrust_merge(src + at, src + mid, src + mid, src + end, dst + at, key);
+        }
+    }
+    if (!ping) memcpy(first, temp, (size_t)n * sizeof(int));
+}
+
+static o_transform identity_transform(void) {                              /* Transform::ResetTransform, transform.h:16-20 */
+    o_transform t; t.position = v1(0); t.rotation = v1(0); t.scale = v1(1); return t;
+}
+
+static void list_bounding_box(const o_bvh *b, const o_bvh_node *leaf, o_aabb *box) { /* HitableList::bounding_box, hitable_list.h:94-118 */
+    o_aabb tmp_box;
+    triangle_GetBV(&b->world->list[b->order[leaf->first]], &tmp_box);
+    *box = tmp_box;
+    for (int i = 1; i < leaf->count; i++) {
+        triangle_GetBV(&b->world->list[b->order[leaf->first + i]], &tmp_box);
+        *box = surrounding_box(*box, tmp_box);
+    }
+}
+
+/* BVHNode::BVHNode(l, n, time0, time1, state), bvh.h:76-125.  [first, first+n) is the node's
+ * span of the pointer array; keys[3][tri] = box.min() of the triangle after GetBV. */
+static int bvh_construct(o_bvh *b, int first, int n, int depth, o_curand_state *state, float *const keys[3], int *temp) {
+    int me = b->n_nodes++;
+    o_bvh_node *node = &b->nodes[me];
+    node->transform = identity_transform();                                /* transform->ResetTransform(), bvh.h:81 */
+    node->depth = depth;
+    int axis = (int)(3 * o_curand_uniform(state));                         /* bvh.h:84 */
+    if (axis == 0) thrust_seq_sort(b->order + first, n, keys[0], temp);    /* BoxCompare(1): x */
+    else if (axis == 1) thrust_seq_sort(b->order + first, n, keys[1], temp);
+    else thrust_seq_sort(b->order + first, n, keys[2], temp);
+    node->axis = axis;
+    if (n == 1 || n == 2) {                                                /* bvh.h:95-109 */
+        node->isLeaf = 1;
+        node->first = first;
+        node->count = n;
+        node->left = node->right = -1;
+        node->list_transform = identity_transform();                       /* childList->transform->ResetTransform() */
+        list_bounding_box(b, node, &node->box);                            /* childList->GetBV(0,1,box) = bounding_box + */
+        TransformAABB(&node->list_transform, &node->box);                  /* TransformAABB of the childList */
+    } else {
+        node->isLeaf = 0;
+        node->first = first;
+        node->count = n;
+        int l = bvh_construct(b, first, n / 2, depth + 1, state, keys, temp);          /* bvh.h:111 */
+        int r = bvh_construct(b, first + n / 2, n - n / 2, depth + 1, state, keys, temp); /* bvh.h:112 */
+        node = &b->nodes[me];
+        node->left = l;
+        node->right = r;
+        o_aabb box_left = b->nodes[l].box, box_right = b->nodes[r].box;    /* GetBV: bounding_box (= box) + TransformAABB */
+        TransformAABB(&b->nodes[l].transform, &box_left);
+        TransformAABB(&b->nodes[r].transform, &box_right);
+        node->box = surrounding_box(box_left, box_right);                  /* bvh.h:121 */
+    }
+    b->nodes[me].skip = b->n_nodes;                                        /* preorder index after this subtree */
+    return me;
+}
+
+o_bvh *o_bvh_build(o_world *world, o_curand_state *state) {                /* create_BVH, createScene.h:42-44 */
+    int n = world->list_size;
+    if (n < 1) return NULL;                                                /* the reference recurses without end on an empty list */
+    o_bvh *b = (o_bvh *)calloc(1, sizeof(o_bvh));
+    b->world = world;
+    b->order = (int *)malloc((size_t)n * sizeof(int));
+    b->cap = 2 * n;
+    b->nodes = (o_bvh_node *)calloc((size_t)b->cap, sizeof(o_bvh_node));
+    float *keys[3];
+    for (int a = 0; a < 3; a++) keys[a] = (float *)malloc((size_t)n * sizeof(float));
+    for (int i = 0; i < n; i++) {
+        b->order[i] = i;
+        o_aabb box;
+        triangle_GetBV(&world->list[i], &box);                             /* ah->GetBV(0, 0, box_left), bvh.h:19 */
+        for (int a = 0; a < 3; a++) keys[a][i] = box._min.e[a];
+    }
+    int *temp = (int *)malloc((size_t)n * sizeof(int));
+    bvh_construct(b, 0, n, 0, state, keys, temp);
+    free(temp);
+    for (int a = 0; a < 3; a++) free(keys[a]);
+    return b;
+}
+
+void o_bvh_free(o_bvh *b) {
+    if (!b) return;
+    free(b->order);
+    free(b->nodes);
+    free(b);
+}
+
+int o_bvh_node_count(const o_bvh *b) { return b->n_nodes; }
+const o_bvh_node *o_bvh_nodes(const o_bvh *b) { return b->nodes; }
+const int *o_bvh_order(const o_bvh *b) { return b->order; }
+
+static void bvh_update(o_bvh *b, int me) {                                 /* BVHNode::UpdateBVH, bvh.h:135-158 */
+    o_bvh_node *node = &b->nodes[me];
+    if (node->isLeaf) {
+        list_bounding_box(b, node, &node->box);                            /* childList->bounding_box(0, 1, box): no TransformAABB here */
+    } else {
+        bvh_update(b, node->left);
+        bvh_update(b, node->right);
+        o_aabb box_left = b->nodes[node->left].box, box_right = b->nodes[node->right].box;
+        TransformAABB(&b->nodes[node->left].transform, &box_left);
+        TransformAABB(&b->nodes[node->right].transform, &box_right);
+        node->box = surrounding_box(box_right, box_left);                  /* bvh.h:155 */
+    }
+}
+
+void o_bvh_update(o_bvh *b) { bvh_update(b, 0); }                          /* Update_BVH, createScene.h:46-58 */
+
+static int leaf_list_hit(const o_bvh *b, const o_bvh_node *leaf, const o_ray *r, float t_min, float t_max, o_hitrec *rec, int *index) {
+    /* childList->hit(...): Hitable::hit on the leaf's HitableList (hitable.h:29-38) + HitableList::collision_detection */
+    o_ray tr = TransformRay(&leaf->list_transform, r);
+    o_hitrec tmp_rec;
+    memset(&tmp_rec, 0, sizeof tmp_rec);
+    int hit_anything = 0;
+    double closest_so_far = t_max;
+    for (int i = 0; i < leaf->count; i++) {
+        int tri = b->order[leaf->first + i];
+        if (triangle_hit(&b->world->list[tri], &tr, t_min, (float)closest_so_far, &tmp_rec) && tmp_rec.t < closest_so_far) {
+            hit_anything = 1;
+            closest_so_far = tmp_rec.t;
+            *rec = tmp_rec;
+            rec->tri = tri;
+            if (index) *index = tri;
+        }
+    }
+    rec->normal = rotate(rec->normal, leaf->list_transform.rotation);
+    return hit_anything;
+}
+
+static int bvh_node_hit(const o_bvh *b, int me, const o_ray *r, float t_min, float t_max, o_hitrec *rec, int *index);
+
+static int bvh_collision_detection(const o_bvh *b, int me, const o_ray *r, float t_min, float t_max, o_hitrec *rec, int *index) { /* bvh.h:160-190 */
+    const o_bvh_node *node = &b->nodes[me];
+    if (!aabb_hit(&node->box, r, t_min, t_max)) return 0;
+    if (node->isLeaf) return leaf_list_hit(b, node, r, t_min, t_max, rec, index);
+
+    o_hitrec left_rec, right_rec;
+    memset(&left_rec, 0, sizeof left_rec);
+    memset(&right_rec, 0, sizeof right_rec);
+    int li = -1, ri = -1;
+    int hit_left = bvh_node_hit(b, node->left, r, t_min, t_max, &left_rec, &li);
+    int hit_right = bvh_node_hit(b, node->right, r, t_min, t_max, &right_rec, &ri);
+    if (hit_left && hit_right) {
+        if (left_rec.t < right_rec.t) { *rec = left_rec; if (index) *index = li; }
+        else { *rec = right_rec; if (index) *index = ri; }
+        return 1;
+    } else if (hit_left) {
+        *rec = left_rec; if (index) *index = li;
+        return 1;
+    } else if (hit_right) {
+        *rec = right_rec; if (index) *index = ri;
+        return 1;
+    }
+    return 0;
+}
+
+static int bvh_node_hit(const o_bvh *b, int me, const o_ray *r, float t_min, float t_max, o_hitrec *rec, int *index) { /* Hitable::hit, hitable.h:29-38 */
+    o_ray tr = TransformRay(&b->nodes[me].transform, r);
+    int flag = bvh_collision_detection(b, me, &tr, t_min, t_max, rec, index);
+    rec->normal = rotate(rec->normal, b->nodes[me].transform.rotation);
+    return flag;
+}
+
+int o_bvh_hit(const o_bvh *bvh, const float origin[3], const float direction[3],
+              float *t_out, int *index_out, float normal_out[3]) {
+    o_ray r = make_ray(v3(origin[0], origin[1], origin[2]), v3(direction[0], direction[1], direction[2]), 0.0f);
+    o_hitrec rec;
+    memset(&rec, 0, sizeof rec);
+    int idx = -1;
+    int flag = bvh_node_hit(bvh, 0, &r, 0.001f, FLT_MAX, &rec, &idx);
     if (t_out) *t_out = rec.t;
     if (index_out) *index_out = flag ? idx : -1;
     if (normal_out) { normal_out[0] = rec.normal.e[0]; normal_out[1] = rec.normal.e[1]; normal_out[2] = rec.normal.e[2]; }
@@ -423,11 +712,21 @@ static o_vec3 backgroundSky(o_vec3 d) {                                   /* ren
     return lerp3(t, v1(1), v3(0.5f, 0.7f, 1.0f));
 }
 
-static o_vec3 LambertShade(const o_ray *r, const o_world *world, int depth, o_curand_state *state, int frameIndex) { /* render.h:70-87 */
+/* Hitable** world of the render kernel: the triangle list itself (renderListAnimation,
+ * render.h:179) or the BVH built over it (renderBVHAnimation, render.h:222). */
+typedef struct { const o_world *list; const o_bvh *bvh; } o_scene_ref;
+
+static int scene_hit(const o_scene_ref *sc, const o_ray *r, float t_min, float t_max, o_hitrec *rec) {   /* (*world)->hit(...) */
+    if (sc->bvh) return bvh_node_hit(sc->bvh, 0, r, t_min, t_max, rec, NULL);
+    return world_hit(sc->list, r, t_min, t_max, rec, NULL);
+}
+
+static o_vec3 LambertShade(const o_ray *r, const o_scene_ref *sc, int depth, o_curand_state *state, int frameIndex) { /* render.h:70-87 */
     (void)depth; (void)frameIndex;
+    const o_world *world = sc->list;
     o_hitrec rec;
     memset(&rec, 0, sizeof rec);
-    if (world_hit(world, r, 0.001, FLT_MAX, &rec, NULL)) {
+    if (scene_hit(sc, r, 0.001, FLT_MAX, &rec)) {
         o_ray scattered;
         o_vec3 attenuation;
         o_vec3 emitted = v3(0, 0, 0); /* Material::emitted, material.h:49-53 */
@@ -440,9 +739,9 @@ static o_vec3 LambertShade(const o_ray *r, const o_world *world, int depth, o_cu
     }
 }
 
-void o_render_window(float *colorBuffer, const o_world *world, const o_camera *camera,
-                     o_curand_state *state, int nx, int ny, int samples, int max_depth,
-                     int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
+static void render_window(float *colorBuffer, const o_scene_ref *world, const o_camera *camera,
+                          o_curand_state *state, int nx, int ny, int samples, int max_depth,
+                          int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
     /* render.h:105-129, one "thread" after another in pixel_index order */
     for (int y = row_begin; y < row_end; y++)
         for (int x = col_begin; x < col_end; x++) {
@@ -465,6 +764,20 @@ void o_render_window(float *colorBuffer, const o_world *world, const o_camera *c
             colorBuffer[3 * (size_t)pixel_index + 1] = c.e[1];
             colorBuffer[3 * (size_t)pixel_index + 2] = c.e[2];
         }
+}
+
+void o_render_window(float *colorBuffer, const o_world *world, const o_camera *camera,
+                     o_curand_state *state, int nx, int ny, int samples, int max_depth,
+                     int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
+    o_scene_ref sc = {world, NULL};                                       /* renderListAnimation, render.h:179 */
+    render_window(colorBuffer, &sc, camera, state, nx, ny, samples, max_depth, frameIndex, row_begin, row_end, col_begin, col_end);
+}
+
+void o_render_window_bvh(float *colorBuffer, const o_bvh *bvh, const o_camera *camera,
+                         o_curand_state *state, int nx, int ny, int samples, int max_depth,
+                         int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
+    o_scene_ref sc = {bvh->world, bvh};                                   /* renderBVHAnimation, render.h:222 */
+    render_window(colorBuffer, &sc, camera, state, nx, ny, samples, max_depth, frameIndex, row_begin, row_end, col_begin, col_end);
 }
 
 void o_render(float *colorBuffer, const o_world *world, const o_camera *camera,

@@ -62,6 +62,22 @@ typedef struct {
     o_vec3 albedo;
 } o_world;
 
+/* core/aabb.h:14-55 */
+typedef struct { o_vec3 _min, _max; } o_aabb;
+
+/* hitable/bvh.h:48-73 BVHNode, flattened: nodes are stored in preorder (a node, its left
+ * subtree, its right subtree), children and leaves are indices.  A leaf's HitableList
+ * (childList, 1 or 2 triangles) is the span [first, first+count) of the sorted pointer array. */
+typedef struct {
+    o_transform transform;        /* BVHNode's own Transform (reset to identity, bvh.h:81) */
+    o_transform list_transform;   /* leaf: childList's Transform (reset, bvh.h:97,103) */
+    o_aabb box;
+    int isLeaf, left, right;      /* children: node indices, -1 in a leaf */
+    int first, count;             /* span of the pointer array this node was built from */
+    int depth, axis, skip;        /* depth of the node (root 0); axis drawn at bvh.h:84; preorder index after the subtree */
+} o_bvh_node;
+typedef struct o_bvh o_bvh;
+
 /* ---- RNG: curand_init / curand / curand_uniform (core/deviceManage.h:127, render.h:116) */
 void o_curand_init(unsigned long long seed, unsigned long long subsequence,
                    unsigned long long offset, o_curand_state *state);
@@ -104,6 +120,26 @@ void o_render_window(float *colorBuffer, const o_world *world, const o_camera *c
 void o_render(float *colorBuffer, const o_world *world, const o_camera *camera,
               o_curand_state *state, int nx, int ny, int samples, int max_depth,
               int frameIndex);
+
+/* ---- BVH: create_BVH (createScene.h:42-44) = new BVHNode(list->list, list_size, 0, 1, state)
+ * (hitable/bvh.h:76-125).  `state` is the pointer the reference passes — the BASE of the
+ * curandState array (kernel.cu:36, createScene.h:212-215), i.e. stream 0, which every node
+ * advances by one draw for its split axis.  The world's triangles are referenced, not copied:
+ * o_world_update_pose + o_bvh_update = updateFBXObj + Update_BVH (render.h:201-207).
+ * NULL when the list is empty (the reference recurses without end). */
+o_bvh *o_bvh_build(o_world *world, o_curand_state *state);
+void o_bvh_update(o_bvh *bvh);                       /* BVHNode::UpdateBVH, bvh.h:135-158 */
+void o_bvh_free(o_bvh *bvh);
+int o_bvh_node_count(const o_bvh *bvh);
+const o_bvh_node *o_bvh_nodes(const o_bvh *bvh);
+const int *o_bvh_order(const o_bvh *bvh);            /* order[slot] = triangle index after the in-place sorts */
+int o_bvh_hit(const o_bvh *bvh, const float origin[3], const float direction[3],
+              float *t_out, int *index_out, float normal_out[3]);
+/* the render kernel with world = the BVH (renderBVHAnimation, core/render.h:191-237) */
+void o_render_window_bvh(float *colorBuffer, const o_bvh *bvh, const o_camera *camera,
+                         o_curand_state *state, int nx, int ny, int samples, int max_depth,
+                         int frameIndex, int row_begin, int row_end, int col_begin,
+                         int col_end);
 
 /* Diagnostics for tests: closest hit of ONE ray through the world list
  * (core/render.h:75 -> hitable.h:29-38 -> hitable_list.h:76-91). Returns hit flag. */

@@ -34,3 +34,19 @@ def crt_built():
     if not os.path.exists(_lib.library_path()):
         _lib.build_library()
     return _lib.lib()
+
+
+@pytest.fixture(scope="session")
+def gpu(crt_built):
+    """torch with a usable HIP device (GPU tests only).  Fails — never skips — without one: the
+    product has no CPU fallback.  A fresh box can take a moment to expose the device to torch."""
+    if crt_built.crt_device_count() < 1:
+        pytest.fail("no HIP device visible: the product has no CPU fallback")
+    import time
+    import torch
+    for _ in range(10):
+        if torch.cuda.is_available():
+            break
+        time.sleep(2.0)
+    assert torch.cuda.is_available()
+    return torch

@@ -19,15 +19,6 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def gpu(crt_built):
-    if crt_built.crt_device_count() < 1:
-        pytest.fail("no HIP device visible: the product has no CPU fallback")
-    import torch
-    assert torch.cuda.is_available()
-    return torch
-
-
-@pytest.fixture(scope="module")
 def obj_dir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("baseline_obj"))
 

@@ -13,15 +13,6 @@ from cudaraytracer_amd import _lib, api, scenes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu(crt_built):
-    if crt_built.crt_device_count() < 1:
-        pytest.fail("no HIP device visible: the product has no CPU fallback")
-    import torch
-    assert torch.cuda.is_available()
-    return torch
-
-
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 

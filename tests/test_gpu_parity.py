@@ -12,20 +12,6 @@ from cudaraytracer_amd import _lib, api, scenes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu(crt_built):
-    if crt_built.crt_device_count() < 1:
-        pytest.fail("no HIP device visible: the product has no CPU fallback")
-    import time
-    import torch
-    for _ in range(5):                     # a fresh box can take a moment to expose the device to torch
-        if torch.cuda.is_available():
-            break
-        time.sleep(2.0)
-    assert torch.cuda.is_available()
-    return torch
-
-
 VARIANTS = {"brute": 1, "tiled": 2, "tiled_tinycaps": 3, "tiled_scalar_light": 4}
 
 
