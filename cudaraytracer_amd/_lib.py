@@ -67,6 +67,16 @@ PROTOTYPES = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "crt_render_strips": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "crt_scene_build_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "crt_scene_refit_bvh": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "crt_scene_bvh_node_count": (C.c_int, [C.c_void_p]),
+    "crt_render_rows_bvh": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "crt_render_strips_bvh": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "crt_debug_bvh_export": (C.c_int, [C.c_void_p, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "crt_write_timing_csv": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.c_double]),
     "crt_render": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.POINTER(CrtCamera), C.c_uint64, _fp]),
     "crt_set_kernel_variant": (C.c_int, [C.c_int]),

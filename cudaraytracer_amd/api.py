@@ -6,6 +6,9 @@ reference (paths relative to CudaTest/src):
     create_FBXMesh                  createScene.h:192-210  (mesh arrays instead of an FBXObject)
     SetCurandState                  core/deviceManage.h:130-136
     renderListAnimation             core/render.h:159-189
+    create_BVHfromList / Update_BVH createScene.h:212-219, 46-58
+    renderBVHAnimation / renderBVH  core/render.h:191-237, kernel.cu:24-39
+    writeCSV                        Loader/CSVWriter.h:8-32
     WritePng                        core/render.h:135-157
 
 torch is used only as plumbing: it owns the device colour buffer and the stream.
@@ -90,6 +93,30 @@ class Scene:
         st = C.c_void_p(stream.cuda_stream) if stream is not None else None
         check(_lib.lib().crt_scene_update_pose(self.handle, _fp(pts), len(pts), st))
 
+    def build_bvh(self, curand_state=None, seed=0):
+        """crt_scene_build_bvh: BVHNode over the list (hitable/bvh.h:76-125).  curand_state: the states
+        that hold pixel 0 (stream 0 supplies the split axes and is advanced), or None."""
+        check(_lib.lib().crt_scene_build_bvh(self.handle, curand_state.handle if curand_state is not None else None, int(seed)))
+
+    def refit_bvh(self, stream=None):
+        """crt_scene_refit_bvh: BVHNode::UpdateBVH after update_pose."""
+        sptr = None
+        if stream is not None:
+            sptr = stream if isinstance(stream, int) else stream.cuda_stream
+        check(_lib.lib().crt_scene_refit_bvh(self.handle, C.c_void_p(sptr)))
+
+    def bvh_export(self):
+        """(boxes[n,6], meta[n,4] = skip, first slot, count, depth; slot_triangle[n_tris]) from the device."""
+        n = _lib.lib().crt_scene_bvh_node_count(self.handle)
+        if n < 0:
+            raise CrtError(_lib.CRT_ERR_INVALID, "the scene has no BVH")
+        boxes = np.zeros((n, 6), dtype=np.float32)
+        meta = np.zeros((n, 4), dtype=np.int32)
+        slots = np.zeros(self.n_triangles, dtype=np.int32)
+        check(_lib.lib().crt_debug_bvh_export(self.handle, _fp(boxes), meta.ctypes.data_as(C.POINTER(C.c_int)),
+                                              slots.ctypes.data_as(C.POINTER(C.c_int))))
+        return boxes, meta, slots
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().crt_scene_free(self.handle)
@@ -162,15 +189,17 @@ def SetCurandState(nx, ny, seed=0, row_begin=0, row_count=None):
 
 
 def render_rows(scene, camera, curand_state, nx, ny, samples, row_begin, row_count, d_rgb,
-                max_depth=8, frame_index=0, stream=None):
+                max_depth=8, frame_index=0, stream=None, bvh=False):
     """One launch of the render kernel (core/render.h:105-129) on rows
     [row_begin, row_begin+row_count).  d_rgb: torch CUDA float32 tensor with
-    row_count*nx*3 elements (or a raw device pointer int)."""
+    row_count*nx*3 elements (or a raw device pointer int).  bvh: world = the scene's BVH
+    (render.h:222) instead of its triangle list (render.h:179)."""
     ptr = d_rgb if isinstance(d_rgb, int) else d_rgb.data_ptr()
     sptr = None
     if stream is not None:
         sptr = stream if isinstance(stream, int) else stream.cuda_stream
-    check(_lib.lib().crt_render_rows(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny,
+    fn = _lib.lib().crt_render_rows_bvh if bvh else _lib.lib().crt_render_rows
+    check(fn(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny,
                                      samples, max_depth, frame_index, row_begin, row_count,
                                      C.c_void_p(ptr), C.c_void_p(sptr)))
 
@@ -180,14 +209,15 @@ def strip_rows(ny, first_strip, strip_rows_, strip_step):
 
 
 def render_strips(scene, camera, curand_state, nx, ny, samples, first_strip, strip_rows_, strip_step,
-                  d_rgb, max_depth=8, frame_index=0, stream=None):
+                  d_rgb, max_depth=8, frame_index=0, stream=None, bvh=False):
     """The render kernel on the strips first_strip, first_strip+strip_step, ... of strip_rows_
     image rows each (crt_render_strips); d_rgb holds them strip after strip."""
     ptr = d_rgb if isinstance(d_rgb, int) else d_rgb.data_ptr()
     sptr = None
     if stream is not None:
         sptr = stream if isinstance(stream, int) else stream.cuda_stream
-    check(_lib.lib().crt_render_strips(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny,
+    fn = _lib.lib().crt_render_strips_bvh if bvh else _lib.lib().crt_render_strips
+    check(fn(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny,
                                        samples, max_depth, frame_index, first_strip, strip_rows_, strip_step,
                                        C.c_void_p(ptr), C.c_void_p(sptr)))
 
@@ -338,3 +368,67 @@ def renderListAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world,
             WritePng(nx, ny, frameIndex, colorBuffer, folder)
         frames.append(colorBuffer)
     return frames
+
+
+def create_BVHfromList(world, curand_state=None, seed=0):
+    """create_BVHfromList, createScene.h:212-219: the BVH becomes part of `world` (the reference
+    returns a BVHNode** that refers to the list's triangles)."""
+    world.build_bvh(curand_state, seed)
+    return world
+
+
+def Update_BVH(world, stream=None):
+    """Update_BVH(BVHNode**), createScene.h:52-58."""
+    world.refit_bvh(stream)
+
+
+def writeCSV(filename, data):
+    """writeCSV, Loader/CSVWriter.h:8-32, for the rows main()/renderBVH/renderBVHAnimation collect:
+    data[0] = the header, data[1] = ["", "", "", build], then [frame, rendering, update, ""]."""
+    frames = [r for r in data[2:]]
+    n = len(frames)
+    fr = (C.c_int * max(n, 1))(*[int(r[0]) for r in frames])
+    ren = (C.c_double * max(n, 1))(*[float(r[1]) for r in frames])
+    upd = (C.c_double * max(n, 1))(*[float(r[2]) for r in frames])
+    check(_lib.lib().crt_write_timing_csv(os.fsencode(filename), n, fr, ren, upd, float(data[1][3])))
+
+
+def renderBVHAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world, camera, curand_state, data,
+                       write_png=True, folder="images/moveTest", poses=None):
+    """renderBVHAnimation, core/render.h:191-237: per frame [update the mesh pose,] refit the BVH
+    (timed: "update"), launch the render kernel with world = the BVH, synchronise, copy back
+    (timed: "rendering"), WritePng.  Appends [frame, rendering, update, ""] rows to `data`."""
+    import time
+    import torch
+    if not torch.cuda.is_available():
+        raise CrtError(_lib.CRT_ERR_NO_DEVICE, "renderBVHAnimation: no HIP device (no CPU fallback)")
+    d_colorBuffer = torch.zeros(ny * nx * 3, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    frames = []
+    for frameIndex in range(beginFrame, endFrame + 1):
+        if poses is not None:                                   # updateFBXObj(frameIndex, obj, ...), render.h:210
+            world.update_pose(poses[frameIndex], stream=stream)
+        t0 = time.perf_counter()
+        Update_BVH(world, stream)                               # render.h:215
+        torch.cuda.synchronize()
+        update_time = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        render_rows(world, camera, curand_state, nx, ny, samples, 0, ny, d_colorBuffer, max_depth=max_depth,
+                    frame_index=frameIndex, stream=stream, bvh=True)
+        torch.cuda.synchronize()
+        colorBuffer = d_colorBuffer.cpu().numpy().reshape(ny, nx, 3)
+        render_time = time.perf_counter() - t0
+        data.append([str(frameIndex), "%f" % render_time, "%f" % update_time, ""])
+        if write_png:
+            WritePng(nx, ny, frameIndex, colorBuffer, folder)
+        frames.append(colorBuffer)
+    return frames
+
+
+def renderBVH(nx, ny, samples, max_depth, beginFrame, endFrame, fbxList, camera, curand_state, data, **kw):
+    """renderBVH, kernel.cu:24-39: timed BVH build, then renderBVHAnimation."""
+    import time
+    t0 = time.perf_counter()
+    create_BVHfromList(fbxList, curand_state)
+    data.append(["", "", "", "%f" % (time.perf_counter() - t0)])
+    return renderBVHAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, fbxList, camera, curand_state, data, **kw)

@@ -8,8 +8,7 @@
 //   WritePng                  core/render.h:135-157          -> crt_to_rgba8 / crt_write_png
 // There is no CPU compute path in this library: without a HIP device every compute entry
 // point returns CRT_ERR_NO_DEVICE.
-#include "../../include/crt.h"
-#include "crt_device.hpp"
+#include "crt_internal.hpp"
 
 #include <math.h>
 #include <stdarg.h>
@@ -46,39 +45,17 @@ namespace {
 thread_local int g_variant = 0;
 thread_local unsigned long long* g_d_stats = nullptr;   // device counters when stats are enabled
 
-#define fail(...) crt::set_error(__VA_ARGS__)
 
-#define HIP_TRY(expr)                                                                  \
-    do {                                                                               \
-        hipError_t e_ = (expr);                                                        \
-        if (e_ != hipSuccess)                                                          \
-            return fail(CRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                           \
-    } while (0)
 
-// Launch context: everything a render launch writes besides its outputs — the per-frame derived
-// triangle records (exact + classification), the scratch of the tiled variant, the timing events,
-// the cached occupancy — lives here, one context per (device, stream).  Work enqueued on one
-// stream is ordered by the stream, so launches of one context never overlap; launches on
-// different streams or devices use different contexts and share nothing but read-only scene data.
-// Grow-only; freed at process exit.
-struct Context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::mutex mu;                   // host-side: two threads enqueueing on the same stream
-    crt::TiledWork w{};
-    size_t pool_entries = 0, tiles = 0;
-    int n_cus = 0;
-    float* d_rec = nullptr;          // n x 16 derived records (tri_prepass output)
-    float4* d_cls = nullptr;         // 5 planes x n_pad classification records (cls_prepass output)
-    size_t rec_cap = 0, cls_cap = 0; // in triangles
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
-    bool ev_has_mid = false, ev_valid = false;
-    crt::LaunchCache cache;
-};
+}  // namespace
+
+namespace crt_host {
+
+namespace {
 std::mutex g_ctx_mu;
 std::vector<Context*> g_contexts;
 thread_local Context* g_last_ctx = nullptr;   // crt_last_kernel_ms / crt_last_kernel_times: last launch of this thread
+}  // namespace
 
 Context* context_for(int device, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_ctx_mu);
@@ -265,59 +242,9 @@ const std::vector<uint32_t>& jump_table() {
     return table;
 }
 
-// ---------------------------------------------------------------- host vec3 helpers
-struct H3 {
-    float x, y, z;
-};
-H3 h3(const float* p) { return H3{p[0], p[1], p[2]}; }
-H3 hsub(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
-H3 hmul(float t, H3 v) { return H3{t * v.x, t * v.y, t * v.z}; }
-H3 hcross(H3 a, H3 b) {   // core/vec3.h:113-117
-    return H3{(a.y * b.z - a.z * b.y), (-(a.x * b.z - a.z * b.x)), (a.x * b.y - a.y * b.x)};
-}
-H3 hunit(H3 v) {          // core/vec3.h:191-193
-    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
-    return H3{v.x / len, v.y / len, v.z / len};
-}
-// rotate(origin, rotation) of core/vec3.h:200-217, literally (used with rotation 0 only).
-H3 hrotate(H3 o, H3 rot) {
-    float radiansX = (float)((M_PI / 180.) * rot.x);
-    float sin_X = sinf(radiansX), cos_X = cosf(radiansX);
-    float radiansY = (float)((M_PI / 180.) * rot.y);
-    float sin_Y = sinf(radiansY), cos_Y = cosf(radiansY);
-    float radiansZ = (float)(-(M_PI / 180.) * rot.z);
-    float sin_Z = sinf(radiansZ), cos_Z = cosf(radiansZ);
-    H3 r0{cos_Y * cos_Z, -cos_Y * sin_Z, sin_Y};
-    H3 r1{sin_X * sin_Y * cos_Z + cos_X * sin_Z, -sin_X * sin_Y * sin_Z + cos_X * cos_Z, -sin_X * cos_Y};
-    H3 r2{-cos_X * sin_Y * cos_Z + sin_X * sin_Z, cos_X * sin_Y * sin_Z + sin_X * cos_Z, cos_X * cos_Y};
-    return H3{o.x * r0.x + o.y * r0.y + o.z * r0.z, o.x * r1.x + o.y * r1.y + o.z * r1.z,
-              o.x * r2.x + o.y * r2.y + o.z * r2.z};
-}
+}  // namespace crt_host
 
-}  // namespace
-
-struct crt_scene {
-    int n_tris = 0;
-    int device = 0;
-    float albedo[3] = {0, 0, 0};
-    float* d_base = nullptr;      // n x 12: v0 v1 v2 n
-    float* d_shade_n = nullptr;   // n x 3: normal after the two rotate() calls of Hitable::hit
-    int n_pad = 0;                // triangle count rounded up to 64 (plane stride of the classification records)
-    bool tiled_safe = false;      // all coordinates finite and |c| <= 2^38
-    int n_points = 0;             // update_pose: size of the point array the indices refer to
-    int* d_idx = nullptr;         // n x 3 vertex indices, 0-based (as given: idx[0], idx[1], idx[2])
-    float* d_points = nullptr;    // n_points x 3 staging of the current pose
-    float* h_points = nullptr;    // pinned host copy of the caller's array (the caller's buffer is free again on return)
-    hipEvent_t pose_copied = nullptr;   // the last H2D copy out of h_points has finished
-};
-
-struct crt_rng {
-    long long first = 0, count = 0;
-    int nx = 0, strip_rows = 1, strip_step = 1;   // layout (crt_rng_create_strips); contiguous when step == 1
-    int device = 0;
-    uint32_t* d_state = nullptr;  // SoA 6 x count: d, v0..v4
-    uint32_t* d_jump = nullptr;
-};
+using namespace crt_host;
 
 extern "C" {
 
@@ -419,6 +346,8 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
     if (e == hipSuccess) e = hipMalloc(&s->d_base, nalloc * crt::kBaseFloats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&s->d_shade_n, nalloc * 3 * sizeof(float));
     s->n_points = n_points;
+    s->h_base = base;
+    s->h_idx = idx0;
     if (e == hipSuccess) e = hipMalloc(&s->d_idx, nalloc * 3 * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(s->d_idx, idx0.data(), nalloc * 3 * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_base, base.data(), nalloc * crt::kBaseFloats * sizeof(float), hipMemcpyHostToDevice);
@@ -535,6 +464,11 @@ int crt_scene_update_pose(crt_scene* s, const float* new_points, int n_points, v
     HIP_TRY(hipMemcpyAsync(s->d_points, s->h_points, bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(s->pose_copied, stream));
     HIP_TRY(crt::launch_update_pose(s->d_points, s->d_idx, s->n_tris, s->d_base, stream));
+    if (s->bvh)   // the BVH world keeps its triangles in leaf order
+        HIP_TRY(crt::launch_update_pose(s->d_points, s->bvh->d_idx_slots, s->n_tris, s->bvh->d_base_slots, stream));
+    for (int i = 0; i < s->n_tris; ++i)   // host mirror (a later crt_scene_build_bvh sees the current pose)
+        for (int k = 0; k < 3; ++k)
+            memcpy(&s->h_base[(size_t)i * crt::kBaseFloats + 3 * k], new_points + 3 * (size_t)s->h_idx[3 * (size_t)i + (2 - k)], 3 * sizeof(float));
     s->tiled_safe = finite && max_abs <= 274877906944.0f;   // 2^38, as at creation (here over all points)
     return CRT_OK;
 }
@@ -549,6 +483,7 @@ void crt_scene_free(crt_scene* s) {
     if (s->d_points) (void)hipFree(s->d_points);
     if (s->h_points) (void)hipHostFree(s->h_points);
     if (s->pose_copied) (void)hipEventDestroy(s->pose_copied);
+    delete s->bvh;
     delete s;
 }
 
@@ -645,8 +580,9 @@ int crt_set_kernel_variant(int variant) {
 }
 
 namespace {
+// world: 0 = the triangle list (renderListAnimation, render.h:179), 1 = the BVH over it (renderBVHAnimation, render.h:222)
 int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny, int samples,
-                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_);
+                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_, int world = 0);
 }
 
 int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
@@ -673,6 +609,30 @@ int crt_render_strips(const crt_scene* scene, const crt_camera* camera, crt_rng*
                        strip_row_count(ny, row_begin, strip_rows, strip_step), strip_rows, strip_step, d_rgb, stream_);
 }
 
+int crt_render_rows_bvh(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
+                        int samples, int max_depth, int frame_index, int row_begin, int row_count,
+                        float* d_rgb, void* stream_) {
+    (void)max_depth;
+    (void)frame_index;
+    if (nx <= 0 || ny <= 0 || samples < 0 || row_begin < 0 || row_count <= 0 || row_begin + row_count > ny)
+        return fail(CRT_ERR_INVALID, "crt_render_rows_bvh: bad image/row range (nx=%d ny=%d rows %d+%d)", nx, ny, row_begin, row_count);
+    return render_impl(scene, camera, rng, nx, ny, samples, row_begin, row_count, 32, 1, d_rgb, stream_, 1);
+}
+
+int crt_render_strips_bvh(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
+                          int samples, int max_depth, int frame_index, int first_strip, int strip_rows,
+                          int strip_step, float* d_rgb, void* stream_) {
+    (void)max_depth;
+    (void)frame_index;
+    if (nx <= 0 || ny <= 0 || samples < 0 || first_strip < 0 || strip_rows <= 0 || strip_step <= 0 ||
+        (strip_step > 1 && strip_rows % 32 != 0) || (long long)first_strip * strip_rows >= ny)
+        return fail(CRT_ERR_INVALID, "crt_render_strips_bvh: bad strip layout (first %d, rows %d, step %d, ny %d)",
+                    first_strip, strip_rows, strip_step, ny);
+    const int row_begin = first_strip * strip_rows;
+    return render_impl(scene, camera, rng, nx, ny, samples, row_begin,
+                       strip_row_count(ny, row_begin, strip_rows, strip_step), strip_rows, strip_step, d_rgb, stream_, 1);
+}
+
 int crt_strip_rows(int ny, int first_strip, int strip_rows, int strip_step) {
     if (ny <= 0 || first_strip < 0 || strip_rows <= 0 || strip_step <= 0) return CRT_ERR_INVALID;
     return strip_row_count(ny, first_strip * strip_rows, strip_rows, strip_step);
@@ -680,8 +640,9 @@ int crt_strip_rows(int ny, int first_strip, int strip_rows, int strip_step) {
 
 namespace {
 int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny, int samples,
-                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_) {
+                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_, int world) {
     if (!scene || !camera || !rng || !d_rgb) return fail(CRT_ERR_INVALID, "crt_render_rows: null argument");
+    if (world == 1 && !scene->bvh) return fail(CRT_ERR_INVALID, "crt_render_rows_bvh: the scene has no BVH (crt_scene_build_bvh)");
     if ((long long)nx * ny > 0x7fffffffLL)
         return fail(CRT_ERR_INVALID, "crt_render_rows: nx*ny exceeds the reference's int pixel_index (core/render.h:111)");
     if (camera->lens_radius != 0.0f)
@@ -716,7 +677,8 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         HIP_TRY(hipEventCreate(&cx.ev_mid));
     }
     HIP_TRY(hipEventRecord(cx.ev_start, stream));   // the per-frame prepasses count as binning time
-    HIP_TRY(crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, cx.d_rec, stream));
+    HIP_TRY(crt::launch_tri_prepass(world == 1 ? scene->bvh->d_base_slots : scene->d_base, scene->n_tris, camera->origin,
+                                    cx.d_rec, stream));
 
     // public variant numbering (crt_set_kernel_variant): 0 auto, 1 brute force, 2 tiled,
     // 3 tiled with tiny list capacities (exercises the overflow fallbacks)
@@ -748,6 +710,23 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     p.rny = 1.0f / (float)ny;
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
 
+    if (world == 1) {
+        // fast arithmetic of the traversal: bounded scene and origin, no nonzero coordinate below 2^-56
+        // (crt_bvh_kernels.hpp: box_hit_fast); otherwise the literal IEEE loop
+        bool fast = scene->tiled_safe && scene->bvh->coords_not_tiny;
+        for (int k = 0; k < 3; ++k) {
+            const float o = camera->origin[k];
+            fast = fast && std::isfinite(o) && fabsf(o) <= 274877906944.0f && (o == 0.0f || fabsf(o) >= 1.3877787807814457e-17f);
+            fast = fast && std::isfinite(camera->lower_left_corner[k]) && std::isfinite(camera->horizontal[k]) && std::isfinite(camera->vertical[k]);
+        }
+        const int force_mode = g_variant == 5 ? 1 : (g_variant == 6 ? 2 : 0);
+        HIP_TRY(crt::launch_render_bvh(p, scene->bvh->d_nodes, scene->bvh->n_nodes, scene->bvh->rot, cx.d_rec,
+                                       scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, fast, force_mode, stream));
+        cx.ev_has_mid = false;
+        HIP_TRY(hipEventRecord(cx.ev_stop, stream));
+        cx.ev_valid = true;
+        return CRT_OK;
+    }
     if (kernel_variant != 0) {
         int rc = ensure_workspace(cx, nx, row_count);
         if (rc != CRT_OK) return rc;

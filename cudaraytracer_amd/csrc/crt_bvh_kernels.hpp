@@ -1,0 +1,320 @@
+// crt_bvh_kernels.hpp — BVH world of the render kernel (included by crt_kernels.hip, namespace crt).
+//
+// Reference: BVHNode::collision_detection (hitable/bvh.h:160-190) under Hitable::hit
+// (hitable/hitable.h:29-38), AABB::hit (core/aabb.h:30-43), launched as the same `render` kernel
+// with world = BVHNode** (core/render.h:222); BVHNode::UpdateBVH (bvh.h:135-158) for the refit.
+//
+// What the reference does per ray is reproduced bit for bit; how it is done is not:
+//   * The reference recurses through device-heap BVHNode objects (two virtual calls and a
+//     TransformRay — normalisation, 18 sin/cos — per node).  Here the tree is a flat array in
+//     preorder (host-built, crt_bvh.cpp) with skip links: a lane walks it without a stack — a node
+//     whose box is hit is followed by its left child (the next node), anything else by the node
+//     after its subtree.  The reference visits BOTH children of every hit node with the same
+//     [t_min, t_max] = [0.001, FLT_MAX] and merges afterwards, so the set of visited nodes does not
+//     depend on the order or on earlier hits: the stackless walk visits exactly that set.
+//   * Every nesting level re-normalises the ray direction (Hitable::hit -> ScaleRay,
+//     transform.h:50-54) and applies rotate(., 0) (vec3.h:200-217): the box of a node at depth L
+//     sees F^(L+1)(d0), a leaf's triangles F^(L+3)(d0), F = rotate0 o unit_vector.  In float F
+//     reaches a fixed point after three applications for 99.99 % of camera rays, and a 2-cycle
+//     for most of the rest; the chain is computed once per ray (c1..c4, c5 when needed) and a
+//     node picks its element by depth.  A wave whose lanes all have c4 == c3 runs the hot loop
+//     (one direction, precomputed reciprocals); any other wave runs the general loop (per-node
+//     selection, literal IEEE divisions, iteration from c4 for chains that do neither).
+//   * Merge rule: `left.t < right.t ? left : right` up the tree (bvh.h:172-179) and the leaf
+//     list's strict `<` (hitable_list.h:84) give: smallest t; among equal t the LAST leaf in
+//     left-to-right order, inside a leaf the first triangle.  Accepted hits never carry a NaN t
+//     (the leaf's `tmp_rec.t < closest_so_far` rejects it), so folding the leaves in preorder
+//     with `keep best unless !(best.t < t)` is the same function.
+//   * Leaf triangles are stored in leaf order ("slots"), so a leaf is a span of the per-frame
+//     exact records (tri_prepass over the slot-ordered base array) and of the shading normals
+//     (rotate(., 0) applied depth + 3 times on the host).
+#pragma once
+
+// node i = 2 float4:  n0 = (min.x, min.y, min.z, max.x),  n1 = (max.y, max.z, skip, info)
+//   skip: preorder index of the node after this node's subtree (as int bits)
+//   info: first slot (bits 0..23) | triangle count (24..25; 0 = inner node) | depth (26..30)
+struct BvhView {
+    const float4* nodes;
+    int n_nodes;
+    float rot[9];   // rows of rotate(., vec3(0)) as the reference computes them (host, crt_bvh.cpp)
+};
+
+__device__ __forceinline__ V3 rot0(const float* m, V3 v) {   // vec3.h:215: ((origin * rotate_k).sum()) = (x*a + y*b) + z*c
+    return V3{(v.x * m[0] + v.y * m[1]) + v.z * m[2], (v.x * m[3] + v.y * m[4]) + v.z * m[5],
+              (v.x * m[6] + v.y * m[7]) + v.z * m[8]};
+}
+
+// rotate(v, 0) returns v bit for bit unless a component is zero (its sign can change) or not
+// finite (NaN appears): only then is the literal product evaluated — for the whole wavefront,
+// which is harmless for the lanes that did not need it.
+__device__ __forceinline__ V3 rot0_exact(const float* m, V3 v) {
+    const float lo = fminf(fminf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)), hi = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
+    const bool plain = lo > 0.0f && hi < __builtin_inff();
+    if (__builtin_amdgcn_ballot_w64(!plain) != 0ull) return rot0(m, v);
+    return v;
+}
+
+// F = RotateRay(ScaleRay(.)) on the direction, identity transform: scale 1 (x / 1 == x), unit_vector, rotate(., 0).
+template <bool FAST>
+__device__ __forceinline__ V3 chain_next(const float* m, V3 c) {
+    return rot0_exact(m, FAST ? unit_vector_fast(c) : unit_vector(c));
+}
+
+__device__ __forceinline__ bool same_bits(V3 a, V3 b) {
+    return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+           __float_as_uint(a.z) == __float_as_uint(b.z);
+}
+
+// AABB::hit (core/aabb.h:30-43), literal: IEEE divisions, ffmin/ffmax as `a < b ? a : b`.
+__device__ __forceinline__ bool box_hit_ieee(float4 n0, float4 n1, V3 o, V3 d) {
+    const float mn[3] = {n0.x, n0.y, n0.z}, mx[3] = {n0.w, n1.x, n1.y};
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    float t_min = 0.001f, t_max = FLT_MAX;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float qa = (mn[a] - oo[a]) / dd[a], qb = (mx[a] - oo[a]) / dd[a];
+        const float t0 = qa < qb ? qa : qb;
+        const float t1 = qa > qb ? qa : qb;
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+// The same test for bounded scenes and ordinary directions (every |d| component >= 2^-40, every
+// coordinate difference 0 or >= 2^-80 in magnitude, <= 2^40: guaranteed by the host's scene check):
+// the six quotients are div_by_rcp (bit-identical to IEEE, see there), all of them are finite, so
+// ffmin/ffmax are v_min/v_max and — t_min only grows, t_max only shrinks — the three early exits
+// are one comparison at the end.
+__device__ __forceinline__ bool box_hit_fast(float4 n0, float4 n1, V3 o, V3 d, V3 y) {
+    const float ax = div_by_rcp(n0.x - o.x, d.x, y.x), bx = div_by_rcp(n0.w - o.x, d.x, y.x);
+    const float ay = div_by_rcp(n0.y - o.y, d.y, y.y), by = div_by_rcp(n1.x - o.y, d.y, y.y);
+    const float az = div_by_rcp(n0.z - o.z, d.z, y.z), bz = div_by_rcp(n1.y - o.z, d.z, y.z);
+    const float t_min = fmaxf(fmaxf(fminf(ax, bx), 0.001f), fmaxf(fminf(ay, by), fminf(az, bz)));
+    const float t_max = fminf(fminf(fmaxf(ax, bx), FLT_MAX), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    return !(t_max <= t_min);
+}
+
+// Triangle::collision_detection (shapes/triangle.h:57-100) on one slot's exact record, per lane.
+template <bool FAST>
+__device__ __forceinline__ bool tri_hit_lane(const float* __restrict__ rec, int slot, V3 d, float& t_out) {
+    const float4* r = reinterpret_cast<const float4*>(rec + (size_t)slot * kRecFloats);
+    const float4 ra = r[0], rb = r[1], rc = r[2], rd = r[3];   // n.xyz e2.x | e2.yz e1.xy | e1.z s.xyz | q.xyz tq
+    if (d.x * ra.x + d.y * ra.y + d.z * ra.z < 0.0f) return false;            // triangle.h:61
+    const float e2x = ra.w, e2y = rb.x, e2z = rb.y, e1x = rb.z, e1y = rb.w, e1z = rc.x;
+    const float hx = (d.y * e2z - d.z * e2y);                                 // triangle.h:71-72
+    const float hy = (-(d.x * e2z - d.z * e2x));
+    const float hz = (d.x * e2y - d.y * e2x);
+    const float a = e1x * hx + e1y * hy + e1z * hz;
+    if (a > -kTriEpsilon && a < kTriEpsilon) return false;                    // triangle.h:77
+    const float f = reciprocal<FAST>(a);                                      // triangle.h:80
+    const float u = f * (rc.y * hx + rc.z * hy + rc.w * hz);                  // triangle.h:82
+    if (u < 0.0f || u > 1.0f) return false;                                   // triangle.h:84
+    const float v = f * (d.x * rd.x + d.y * rd.y + d.z * rd.z);               // triangle.h:88
+    if (v < 0.0f || u + v > 1.0f) return false;                               // triangle.h:89
+    t_out = f * rd.w;                                                         // triangle.h:92
+    return true;
+}
+
+// A leaf's HitableList (1 or 2 triangles, hitable_list.h:76-91: strict <, t_max = FLT_MAX) folded
+// into the running result with the tree's merge rule (bvh.h:172-179).
+template <bool FAST>
+__device__ __forceinline__ void leaf_hit(const float* __restrict__ rec, int first, int count, V3 d, float& best_t, int& best_slot) {
+    float closest = FLT_MAX;
+    int slot = -1;
+    for (int j = 0; j < count; ++j) {
+        float t;
+        if (tri_hit_lane<FAST>(rec, first + j, d, t) && t < closest) {
+            closest = t;
+            slot = first + j;
+        }
+    }
+    if (slot >= 0 && !(best_slot >= 0 && best_t < closest)) {
+        best_t = closest;
+        best_slot = slot;
+    }
+}
+
+// Hot loop: every lane of the wavefront has c4 == c3 and ordinary components.
+__device__ __forceinline__ void bvh_walk_fast(const BvhView& b, const float* __restrict__ rec, V3 o, V3 c1, V3 c2, V3 c3,
+                                              float& best_t, int& best_slot) {
+    const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
+    int i = 0;
+    while (i < b.n_nodes) {
+        const float4 n0 = b.nodes[2 * (size_t)i], n1 = b.nodes[2 * (size_t)i + 1];
+        const int skip = __float_as_int(n1.z), info = __float_as_int(n1.w);
+        const int depth = (info >> 26) & 31, count = (info >> 24) & 3, first = info & 0xffffff;
+        V3 d = c3, y = y3;
+        if (depth < 2) {   // the root sees F(d0), its children F^2(d0): three nodes of the whole tree
+            d = depth == 0 ? c1 : c2;
+            y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
+        }
+        const bool hit = box_hit_fast(n0, n1, o, d, y);
+        if (hit && count != 0) leaf_hit<true>(rec, first, count, c3, best_t, best_slot);   // triangles see F^(depth+3) = c3
+        i = (hit && count == 0) ? i + 1 : skip;
+    }
+}
+
+// General loop: chain element by depth, literal arithmetic.  mode: 0 = c_k is c4 for k > 4 (fixed
+// point reached by c4 at the latest), 1 = 2-cycle (c5 == c3: odd k -> c3, even k -> c4), 2 = neither:
+// iterate F from c4.
+template <bool FAST>
+__device__ __forceinline__ V3 chain_at(const float* m, int k, V3 c1, V3 c2, V3 c3, V3 c4, int mode) {
+    if (k <= 1) return c1;
+    if (k == 2) return c2;
+    if (k == 3) return c3;
+    if (k == 4 || mode == 0) return c4;
+    if (mode == 1) return (k & 1) ? c3 : c4;
+    V3 c = c4;
+    for (int j = 4; j < k; ++j) c = rot0(m, unit_vector(c));   // per lane: no wave votes in here
+    return c;
+}
+
+template <bool FAST>
+__device__ __forceinline__ void bvh_walk_general(const BvhView& b, const float* __restrict__ rec, V3 o, V3 c1, V3 c2, V3 c3,
+                                                 V3 c4, int mode, float& best_t, int& best_slot) {
+    int i = 0;
+    while (i < b.n_nodes) {
+        const float4 n0 = b.nodes[2 * (size_t)i], n1 = b.nodes[2 * (size_t)i + 1];
+        const int skip = __float_as_int(n1.z), info = __float_as_int(n1.w);
+        const int depth = (info >> 26) & 31, count = (info >> 24) & 3, first = info & 0xffffff;
+        const bool hit = box_hit_ieee(n0, n1, o, chain_at<FAST>(b.rot, depth + 1, c1, c2, c3, c4, mode));
+        if (hit && count != 0)
+            leaf_hit<FAST>(rec, first, count, chain_at<FAST>(b.rot, depth + 3, c1, c2, c3, c4, mode), best_t, best_slot);
+        i = (hit && count == 0) ? i + 1 : skip;
+    }
+}
+
+// (*world)->hit(r, 0.001, FLT_MAX, rec) with world = the BVH root, for the lane's ray (o, d0);
+// d1 = unit_vector(d0).  FAST: bounded scene (crt_bvh.cpp: bvh_fast_ok).  force_general: test hook.
+template <bool FAST>
+__device__ __forceinline__ void bvh_trace(const BvhView& b, const float* __restrict__ rec, V3 o, V3 d1, int force_mode,
+                                          float& best_t, int& best_slot) {
+    const V3 c1 = rot0_exact(b.rot, d1);
+    const V3 c2 = chain_next<FAST>(b.rot, c1);
+    const V3 c3 = chain_next<FAST>(b.rot, c2);
+    const V3 c4 = chain_next<FAST>(b.rot, c3);
+    best_t = FLT_MAX;
+    best_slot = -1;
+    bool hot = FAST && force_mode == 0 && same_bits(c4, c3);
+    if (hot) {   // ordinary: every component of the three directions is at least 2^-40 in magnitude (and finite)
+        const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
+                               fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
+        hot = lo >= 9.094947017729282e-13f;
+    }
+    if (__builtin_amdgcn_ballot_w64(!hot) == 0ull) {
+        bvh_walk_fast(b, rec, o, c1, c2, c3, best_t, best_slot);
+        return;
+    }
+    const V3 c5 = chain_next<FAST>(b.rot, c4);
+    int mode = same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2);
+    if (force_mode == 2) mode = 2;   // test hook: every lane iterates F from c4 (must give the same pixels)
+    bvh_walk_general<FAST>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot);
+}
+
+// The render kernel with world = the BVH: lane = pixel, wavefront = 8x8 tile, block = 16x16.
+template <bool FAST>
+__global__ void __launch_bounds__(256)
+render_bvh_kernel(RenderParams p, BvhView b, const float* __restrict__ rec, const float* __restrict__ shade_n,
+                  uint32_t* __restrict__ state, float* __restrict__ rgb, int force_mode) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool valid = x < p.nx && ly < p.row_count;                  // render.h:109
+    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+    const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
+    // lanes off the image replay a valid pixel (unstored): the traversal votes need whole wavefronts
+    render_pixel<FAST, false, false>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, valid,
+                                     [&](V3 d1, V3, float& closest, int& hit_idx) {
+        bvh_trace<FAST>(b, rec, o, d1, force_mode, closest, hit_idx);
+    });
+}
+
+hipError_t launch_render_bvh(const RenderParams& p, const float4* d_nodes, int n_nodes, const float rot[9], const float* d_rec,
+                             const float* d_shade_n, uint32_t* d_state, float* d_rgb, bool fast, int force_mode,
+                             hipStream_t stream) {
+    if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
+    BvhView b;
+    b.nodes = d_nodes;
+    b.n_nodes = n_nodes;
+    for (int k = 0; k < 9; ++k) b.rot[k] = rot[k];
+    dim3 block(256), grid((unsigned)((p.nx + 15) / 16), (unsigned)((p.row_count + 15) / 16));
+    if (fast)
+        hipLaunchKernelGGL(render_bvh_kernel<true>, grid, block, 0, stream, p, b, d_rec, d_shade_n, d_state, d_rgb, force_mode);
+    else
+        hipLaunchKernelGGL(render_bvh_kernel<false>, grid, block, 0, stream, p, b, d_rec, d_shade_n, d_state, d_rgb, force_mode);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ refit (BVHNode::UpdateBVH, bvh.h:135-158)
+// One launch per tree level, deepest first (the reference recurses in one device thread).
+//   leaf:  childList->bounding_box(0, 1, box) (hitable_list.h:94-118): surrounding_box over the
+//          triangles' GetBV = Triangle::bounding_box (triangle.h:102-115) + TransformAABB (transform.h:22-31)
+//   inner: surrounding_box(right->GetBV, left->GetBV), GetBV = the child's box + TransformAABB
+struct BoxF {
+    float mn[3], mx[3];
+};
+
+__device__ __forceinline__ BoxF transform_aabb(const float* m, BoxF bx) {   // transform.h:22-31 with rotation 0, position 0
+    const V3 rmin = rot0(m, V3{bx.mn[0], bx.mn[1], bx.mn[2]}), rmax = rot0(m, V3{bx.mx[0], bx.mx[1], bx.mx[2]});
+    BoxF o;
+    o.mn[0] = fminf(rmin.x, rmax.x) + 0.0f; o.mn[1] = fminf(rmin.y, rmax.y) + 0.0f; o.mn[2] = fminf(rmin.z, rmax.z) + 0.0f;
+    o.mx[0] = fmaxf(rmin.x, rmax.x) + 0.0f; o.mx[1] = fmaxf(rmin.y, rmax.y) + 0.0f; o.mx[2] = fmaxf(rmin.z, rmax.z) + 0.0f;
+    return o;
+}
+
+__device__ __forceinline__ BoxF surrounding(BoxF a, BoxF b) {   // aabb.h:58-66
+    BoxF o;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.mn[k] = fminf(a.mn[k], b.mn[k]); o.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+    return o;
+}
+
+struct RotM {
+    float m[9];
+};
+
+__global__ void __launch_bounds__(256)
+bvh_refit_level_kernel(float4* __restrict__ nodes, const int* __restrict__ level_nodes, int n_level,
+                       const float* __restrict__ base /* slot order */, RotM rot) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_level) return;
+    const int i = level_nodes[j];
+    const float4 n1 = nodes[2 * (size_t)i + 1];
+    const int info = __float_as_int(n1.w);
+    const int count = (info >> 24) & 3, first = info & 0xffffff;
+    BoxF box;
+    if (count != 0) {
+        for (int t = 0; t < count; ++t) {
+            const float* v = base + (size_t)(first + t) * kBaseFloats;
+            BoxF tb;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                tb.mn[k] = fminf(v[k], fminf(v[3 + k], v[6 + k]));
+                tb.mx[k] = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+            }
+            tb = transform_aabb(rot.m, tb);
+            box = (t == 0) ? tb : surrounding(box, tb);
+        }
+    } else {
+        const int l = i + 1;
+        const int r = __float_as_int(nodes[2 * (size_t)l + 1].z);   // the left child's skip = the right child
+        const float4 l0 = nodes[2 * (size_t)l], l1 = nodes[2 * (size_t)l + 1], r0 = nodes[2 * (size_t)r], r1 = nodes[2 * (size_t)r + 1];
+        BoxF bl = {{l0.x, l0.y, l0.z}, {l0.w, l1.x, l1.y}}, br = {{r0.x, r0.y, r0.z}, {r0.w, r1.x, r1.y}};
+        box = surrounding(transform_aabb(rot.m, br), transform_aabb(rot.m, bl));   // bvh.h:155: (box_right, box_left)
+    }
+    nodes[2 * (size_t)i] = make_float4(box.mn[0], box.mn[1], box.mn[2], box.mx[0]);
+    nodes[2 * (size_t)i + 1] = make_float4(box.mx[1], box.mx[2], n1.z, n1.w);
+}
+
+hipError_t launch_bvh_refit_level(float4* d_nodes, const int* d_level_nodes, int n_level, const float* d_base_slots,
+                                  const float rot[9], hipStream_t stream) {
+    if (n_level <= 0) return hipSuccess;
+    RotM r;
+    for (int k = 0; k < 9; ++k) r.m[k] = rot[k];
+    hipLaunchKernelGGL(bvh_refit_level_kernel, dim3((unsigned)((n_level + 255) / 256)), dim3(256), 0, stream, d_nodes, d_level_nodes,
+                       n_level, d_base_slots, r);
+    return hipGetLastError();
+}

@@ -131,6 +131,18 @@ hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, u
                                    hipStream_t stream);
 constexpr int kStatsWords = 48;
 
+// BVH world (crt_bvh_kernels.hpp).  d_nodes: 2 float4 per node, preorder with skip links
+// (layout there); d_rec / d_shade_n are in leaf ("slot") order.  fast: bounded scene (host check).
+// force_mode: 0 = normal, 1 = general loop for every wavefront, 2 = general loop iterating the
+// direction chain from its fourth element (test hooks: all must give the same pixels).
+hipError_t launch_render_bvh(const RenderParams& p, const float4* d_nodes, int n_nodes, const float rot[9], const float* d_rec,
+                             const float* d_shade_n, uint32_t* d_state, float* d_rgb, bool fast, int force_mode,
+                             hipStream_t stream);
+// One level of BVHNode::UpdateBVH: the nodes level_nodes[0..n_level) (all of one depth) recompute
+// their boxes from their triangles (leaves) or children (the deeper levels are already done).
+hipError_t launch_bvh_refit_level(float4* d_nodes, const int* d_level_nodes, int n_level, const float* d_base_slots,
+                                  const float rot[9], hipStream_t stream);
+
 // Sets the calling thread's crt_last_error() text and returns `code` (host layer, crt_api.cpp).
 int set_error(int code, const char* fmt, ...);
 

@@ -1,0 +1,128 @@
+// crt_internal.hpp — host-side internals shared by the translation units of libcrt_hip.so
+// (crt_api.cpp, crt_bvh.cpp, crt_multi.cpp).  Not part of the ABI.
+#pragma once
+
+#include "../../include/crt.h"
+#include "crt_device.hpp"
+
+#include <math.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define fail(...) crt::set_error(__VA_ARGS__)
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(CRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+namespace crt_host {
+
+// Launch context: everything a render launch writes besides its outputs — the per-frame derived
+// triangle records (exact + classification), the scratch of the tiled variant, the timing events,
+// the cached occupancy — lives here, one context per (device, stream).  Work enqueued on one
+// stream is ordered by the stream, so launches of one context never overlap; launches on
+// different streams or devices use different contexts and share nothing but read-only scene data.
+// Grow-only; freed at process exit.
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                   // host-side: two threads enqueueing on the same stream
+    crt::TiledWork w{};
+    size_t pool_entries = 0, tiles = 0;
+    int n_cus = 0;
+    float* d_rec = nullptr;          // n x 16 derived records (tri_prepass output)
+    float4* d_cls = nullptr;         // 5 planes x n_pad classification records (cls_prepass output)
+    size_t rec_cap = 0, cls_cap = 0; // in triangles
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
+    bool ev_has_mid = false, ev_valid = false;
+    crt::LaunchCache cache;
+};
+
+Context* context_for(int device, hipStream_t stream);
+int ensure_records(Context& cx, int n_tris, int n_pad);
+int ensure_workspace(Context& ws, int nx, int rows);
+bool have_device();
+
+// ---------------------------------------------------------------- host vec3 helpers
+struct H3 {
+    float x, y, z;
+};
+inline H3 h3(const float* p) { return H3{p[0], p[1], p[2]}; }
+inline H3 hsub(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 hmul(float t, H3 v) { return H3{t * v.x, t * v.y, t * v.z}; }
+inline H3 hcross(H3 a, H3 b) {   // core/vec3.h:113-117
+    return H3{(a.y * b.z - a.z * b.y), (-(a.x * b.z - a.z * b.x)), (a.x * b.y - a.y * b.x)};
+}
+inline H3 hunit(H3 v) {          // core/vec3.h:191-193
+    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return H3{v.x / len, v.y / len, v.z / len};
+}
+// rotate(origin, rotation) of core/vec3.h:200-217, literally (used with rotation 0 only).
+inline H3 hrotate(H3 o, H3 rot) {
+    float radiansX = (float)((M_PI / 180.) * rot.x);
+    float sin_X = sinf(radiansX), cos_X = cosf(radiansX);
+    float radiansY = (float)((M_PI / 180.) * rot.y);
+    float sin_Y = sinf(radiansY), cos_Y = cosf(radiansY);
+    float radiansZ = (float)(-(M_PI / 180.) * rot.z);
+    float sin_Z = sinf(radiansZ), cos_Z = cosf(radiansZ);
+    H3 r0{cos_Y * cos_Z, -cos_Y * sin_Z, sin_Y};
+    H3 r1{sin_X * sin_Y * cos_Z + cos_X * sin_Z, -sin_X * sin_Y * sin_Z + cos_X * cos_Z, -sin_X * cos_Y};
+    H3 r2{-cos_X * sin_Y * cos_Z + sin_X * sin_Z, cos_X * sin_Y * sin_Z + sin_X * cos_Z, cos_X * cos_Y};
+    return H3{o.x * r0.x + o.y * r0.y + o.z * r0.z, o.x * r1.x + o.y * r1.y + o.z * r1.z,
+              o.x * r2.x + o.y * r2.y + o.z * r2.z};
+}
+
+
+}  // namespace crt_host
+
+// BVH world of a scene (crt_bvh.cpp): the tree flat on the device, triangles in leaf order.
+struct crt_bvh {
+    int n_nodes = 0, max_depth = 0;
+    float4* d_nodes = nullptr;          // 2 float4 per node, preorder (crt_bvh_kernels.hpp)
+    float* d_base_slots = nullptr;      // n x 12 base records in slot order
+    float* d_shade_n_slots = nullptr;   // n x 3 shading normals in slot order (rotate(., 0) applied depth + 3 times)
+    int* d_idx_slots = nullptr;         // n x 3 vertex indices in slot order (update_pose)
+    int* d_level_nodes = nullptr;       // node indices grouped by depth
+    std::vector<int> level_offset;      // level d = d_level_nodes[level_offset[d] .. level_offset[d + 1])
+    std::vector<int> slot_tri;          // slot -> triangle index of the list
+    float rot[9] = {0};                 // rotate(., 0) matrix
+    bool coords_not_tiny = false;       // every nonzero vertex coordinate is >= 2^-56 in magnitude
+    ~crt_bvh();
+};
+
+struct crt_scene {
+    int n_tris = 0;
+    int device = 0;
+    float albedo[3] = {0, 0, 0};
+    float* d_base = nullptr;      // n x 12: v0 v1 v2 n
+    float* d_shade_n = nullptr;   // n x 3: normal after the two rotate() calls of Hitable::hit
+    int n_pad = 0;                // triangle count rounded up to 64 (plane stride of the classification records)
+    bool tiled_safe = false;      // all coordinates finite and |c| <= 2^38
+    int n_points = 0;             // update_pose: size of the point array the indices refer to
+    int* d_idx = nullptr;         // n x 3 vertex indices, 0-based (as given: idx[0], idx[1], idx[2])
+    float* d_points = nullptr;    // n_points x 3 staging of the current pose
+    float* h_points = nullptr;    // pinned host copy of the caller's array (the caller's buffer is free again on return)
+    hipEvent_t pose_copied = nullptr;   // the last H2D copy out of h_points has finished
+    std::vector<float> h_base;    // host mirror of d_base (BVH build)
+    std::vector<int> h_idx;       // host mirror of d_idx
+    crt_bvh* bvh = nullptr;       // crt_scene_build_bvh
+};
+
+struct crt_rng {
+    long long first = 0, count = 0;
+    int nx = 0, strip_rows = 1, strip_step = 1;   // layout (crt_rng_create_strips); contiguous when step == 1
+    int device = 0;
+    uint32_t* d_state = nullptr;  // SoA 6 x count: d, v0..v4
+    uint32_t* d_jump = nullptr;
+};
+

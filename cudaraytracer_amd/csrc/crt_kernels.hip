@@ -463,7 +463,10 @@ __device__ __forceinline__ void exact_test_vec(const RecV& rc, int i_raw, V3 d, 
 // (hitable/hitable_list.h:76-91): minimum t over all triangles that pass
 // Triangle::collision_detection (any sign of t, no range test), lowest index on ties, NaN
 // never accepted.
-template <bool FASTDIV = false, bool SKYONLY = false, class Traverse>
+// `traverse(d1, d2, closest, hit_idx)`: d1 = unit_vector(d0) (what the world-level ScaleRay produces),
+// d2 = unit_vector(d1) (what the triangle-level one produces; computed only if WANT_D2 — the BVH
+// world derives its own per-level directions from d1).
+template <bool FASTDIV = false, bool SKYONLY = false, bool WANT_D2 = true, class Traverse>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly,
                                              const float* __restrict__ shade_n,
                                              uint32_t* __restrict__ state, float* __restrict__ rgb,
@@ -517,11 +520,12 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
         // world list Transform then triangle Transform: ScaleRay normalises twice
         // (transform.h:50-54 via hitable.h:34 at both levels).
         V3 d1 = FASTDIV ? unit_vector_fast(d0) : unit_vector(d0);
-        V3 d2 = FASTDIV ? unit_vector_fast(d1) : unit_vector(d1);
+        V3 d2 = d1;
+        if (WANT_D2) d2 = FASTDIV ? unit_vector_fast(d1) : unit_vector(d1);
 
         float closest = FLT_MAX;   // double closest_so_far = t_max (FLT_MAX), hitable_list.h:82
         int hit_idx = -1;
-        traverse(d2, closest, hit_idx);
+        traverse(d1, d2, closest, hit_idx);
 
         V3 sky = sky_from_unit(d1);                                    // backgroundSky(r.direction())
         if (hit_idx >= 0) {                                            // LambertShade, render.h:75-83
@@ -588,7 +592,7 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
     const int ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);   // row inside the band
     if (x >= p.nx || ly >= p.row_count) return;                        // render.h:109
     const int n_tris = p.n_tris;
-    render_pixel(p, x, ly, shade_n, state, rgb, true, [&](V3 d2, float& closest, int& hit_idx) {
+    render_pixel(p, x, ly, shade_n, state, rgb, true, [&](V3, V3 d2, float& closest, int& hit_idx) {
         walk<FAST>(rec, 0, n_tris, [](int k) { return k; }, d2, closest, hit_idx);
     });
 }
@@ -1255,7 +1259,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             if (wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
                 render_pixel<true>(p, x, ly, shade_n, state, rgb, lane_valid,
-                             [&](V3 d2, float& closest, int& hit_idx) {
+                             [&](V3, V3 d2, float& closest, int& hit_idx) {
                     ray_d[0][lane] = d2.x;
                     ray_d[1][lane] = d2.y;
                     ray_d[2][lane] = d2.z;
@@ -1382,10 +1386,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         const bool pair_mode = n_pairs != 0xffffffffu;
         if (cnt == 0) {   // background only (most tiles of a typical frame)
             if (x < p.nx && ly < p.row_count)
-                render_pixel<true, true>(p, x, ly, shade_n, state, rgb, true, [](V3, float&, int&) {});
+                render_pixel<true, true>(p, x, ly, shade_n, state, rgb, true, [](V3, V3, float&, int&) {});
         } else if (pair_mode) {   // all 64 lanes stay active (ds_bpermute reads lanes); off-image lanes replay a valid pixel, unstored
             render_pixel<true>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, x < p.nx && ly < p.row_count,
-                         [&](V3 d2, float& closest, int& hit_idx) {
+                         [&](V3, V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 lkey[wave][lane] = ~0ull;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1405,7 +1409,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             });
         } else if (x < p.nx && ly < p.row_count) {
             render_pixel<true>(p, x, ly, shade_n, state, rgb, true,
-                         [&](V3 d2, float& closest, int& hit_idx) {
+                         [&](V3, V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (VREC) {
                     trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
@@ -1851,5 +1855,7 @@ hipError_t launch_assemble_strips(const float* d_parts, long long part_stride, i
                            strip_rows, world, d_full);
     return hipGetLastError();
 }
+
+#include "crt_bvh_kernels.hpp"
 
 }  // namespace crt

@@ -184,12 +184,56 @@ int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
                const crt_scene *scene, const crt_camera *camera, uint64_t seed,
                float *rgb_out);
 
+/* ---- BVH world ------------------------------------------------------------------
+ * The reference's shipped configuration (kernel.cu:97): the same `render` kernel and
+ * LambertShade, with world = a BVHNode tree over the triangle list. */
+
+/* replaces: create_BVHfromList -> create_BVH<<<1,1>>> -> BVHNode::BVHNode (createScene.h:42-44,
+ * 212-219; hitable/bvh.h:76-125): median split of the list (n/2 | n - n/2, leaves of 1 or 2
+ * triangles) after sorting every span by box.min() on an axis drawn per node as
+ * int(3 * curand_uniform(state)) from STREAM 0 (create_BVH passes the base of the curandState
+ * array).  rng: the states that hold pixel 0 — stream 0 continues from where it is and is left
+ * one draw per node further, as in the reference; NULL (or states that do not hold pixel 0, e.g.
+ * another rank's strips): a private curand_init(seed, 0, 0) stream is used, which is the same
+ * sequence when the BVH is built right after SetCurandState like the reference does
+ * (kernel.cu:69-71, :36).  The sort is Thrust's sequential merge sort with the reference's
+ * comparator, restated (crt_bvh.cpp; PARITY UNPINNED: the comparator is not a strict weak
+ * ordering, so the order is the algorithm's).  Host-built, uploaded flat; replaces any earlier
+ * BVH of the scene.  CRT_ERR_UNSUPPORTED for an empty list (the reference does not terminate). */
+int crt_scene_build_bvh(crt_scene *scene, crt_rng *rng, uint64_t seed);
+/* replaces: Update_BVH -> UpdateBVH<<<1,1>>> -> BVHNode::UpdateBVH (createScene.h:46-58,
+ * hitable/bvh.h:135-158): boxes recomputed bottom-up from the current triangle vertices (after
+ * crt_scene_update_pose), topology kept.  Enqueued on `stream`. */
+int crt_scene_refit_bvh(crt_scene *scene, void *stream);
+int crt_scene_bvh_node_count(const crt_scene *scene);
+/* replaces: render<<<>>> with world = BVHNode** (core/render.h:222; BVHNode::collision_detection
+ * hitable/bvh.h:160-190, AABB::hit core/aabb.h:30-43).  Arguments as crt_render_rows /
+ * crt_render_strips. */
+int crt_render_rows_bvh(const crt_scene *scene, const crt_camera *camera, crt_rng *rng, int nx,
+                        int ny, int samples, int max_depth, int frame_index, int row_begin,
+                        int row_count, float *d_rgb, void *stream);
+int crt_render_strips_bvh(const crt_scene *scene, const crt_camera *camera, crt_rng *rng, int nx,
+                          int ny, int samples, int max_depth, int frame_index, int first_strip,
+                          int strip_rows, int strip_step, float *d_rgb, void *stream);
+/* Diagnostics: the tree as it is on the device.  boxes6: n_nodes x {min xyz, max xyz}; meta4:
+ * n_nodes x {skip, first slot, triangle count (0 = inner node), depth}, nodes in preorder;
+ * slot_triangle: n_tris list indices in leaf order.  Any pointer may be NULL. */
+int crt_debug_bvh_export(const crt_scene *scene, float *boxes6, int *meta4, int *slot_triangle);
+/* replaces: writeCSV("output.csv", data) (Loader/CSVWriter.h:8-32) with the rows main() and
+ * renderBVHAnimation collect (kernel.cu:61,18,37; core/render.h:232): header
+ * frame,rendering,update,build; one row with the build time; one row per frame with the render
+ * and BVH-update times (seconds, std::to_string format). */
+int crt_write_timing_csv(const char *path, int n_frames, const int *frame, const double *rendering,
+                         const double *update, double build);
+
 /* Kernel selection (diagnostics / A-B benchmarking), per calling thread. 0 = auto (default:
  * tiled when the scene and camera are finite and |coordinate| <= 2^38, else brute force),
  * 1 = brute-force list walk, 2 = tiled, 3 = tiled with a tiny survivor pool and heavy-tile
  * threshold (test hook for the overflow fallback and the shared-tile path), 4 = tiled with
  * scalar-operand (SGPR) list walks instead of the LDS-staged records and per-pixel candidate
- * masks (A/B).  All variants produce identical pixels.  Returns the previous value. */
+ * masks (A/B); BVH world only: 5 = the general traversal loop for every wavefront, 6 = the same
+ * with every direction chain iterated from its fourth element (test hooks for the rare paths).
+ * All variants produce identical pixels.  Returns the previous value. */
 int crt_set_kernel_variant(int variant);
 
 /* Diagnostics of the tiled variant, per calling thread.  out48 (nullable, 48 words) first

@@ -35,6 +35,12 @@ class Camera(C.Structure):
 
 STATE_DTYPE = np.dtype([("d", np.uint32), ("v", np.uint32, (5,))])
 
+# o_bvh_node (crt_oracle.h): 2 transforms (9 floats each), box (6 floats), 8 ints
+BVH_NODE_DTYPE = np.dtype([("transform", np.float32, (9,)), ("list_transform", np.float32, (9,)),
+                           ("box", np.float32, (6,)), ("isLeaf", np.int32), ("left", np.int32), ("right", np.int32),
+                           ("first", np.int32), ("count", np.int32), ("depth", np.int32), ("axis", np.int32),
+                           ("skip", np.int32)])
+
 _lib = None
 
 
@@ -61,6 +67,18 @@ def lib():
         L.o_world_hit.argtypes = [C.c_void_p, fp, fp, fp, C.POINTER(C.c_int), fp]
         L.o_world_hit.restype = C.c_int
         L.o_to_rgba8.argtypes = [fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
+        L.o_bvh_build.argtypes = [C.c_void_p, C.c_void_p]
+        L.o_bvh_build.restype = C.c_void_p
+        L.o_bvh_update.argtypes = [C.c_void_p]
+        L.o_bvh_free.argtypes = [C.c_void_p]
+        L.o_bvh_node_count.argtypes = [C.c_void_p]
+        L.o_bvh_nodes.argtypes = [C.c_void_p]
+        L.o_bvh_nodes.restype = C.c_void_p
+        L.o_bvh_order.argtypes = [C.c_void_p]
+        L.o_bvh_order.restype = C.c_void_p
+        L.o_bvh_hit.argtypes = [C.c_void_p, fp, fp, fp, C.POINTER(C.c_int), fp]
+        L.o_bvh_hit.restype = C.c_int
+        L.o_render_window_bvh.argtypes = [fp, C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_int] * 9
         _lib = L
     return _lib
 
@@ -135,6 +153,68 @@ class World:
         nrm = (C.c_float * 3)()
         flag = lib().o_world_hit(self.handle, _f3(origin), _f3(direction), C.byref(t), C.byref(idx), nrm)
         return bool(flag), np.float32(t.value), idx.value, np.array(list(nrm), dtype=np.float32)
+
+
+class Bvh:
+    """create_BVHfromList (createScene.h:212-219): BVHNode over the world's triangle list.
+    `states` is the curandState array whose element 0 (stream 0) the build draws its split
+    axes from; it is advanced in place."""
+
+    def __init__(self, world, states):
+        self.world = world          # keeps the list alive: the tree references its triangles
+        self.handle = lib().o_bvh_build(world.handle, states.ctypes.data)
+        if not self.handle:
+            raise ValueError("o_bvh_build: empty list")
+
+    def update(self):
+        """Update_BVH (createScene.h:46-58) after world.update_pose."""
+        lib().o_bvh_update(self.handle)
+
+    def nodes(self):
+        n = lib().o_bvh_node_count(self.handle)
+        buf = (C.c_char * (n * BVH_NODE_DTYPE.itemsize)).from_address(lib().o_bvh_nodes(self.handle))
+        return np.frombuffer(buf, dtype=BVH_NODE_DTYPE, count=n).copy()
+
+    def order(self):
+        n = self.world.n_tris
+        buf = (C.c_int * n).from_address(lib().o_bvh_order(self.handle))
+        return np.frombuffer(buf, dtype=np.int32, count=n).copy()
+
+    def hit(self, origin, direction):
+        t = C.c_float()
+        idx = C.c_int()
+        nrm = (C.c_float * 3)()
+        flag = lib().o_bvh_hit(self.handle, _f3(origin), _f3(direction), C.byref(t), C.byref(idx), nrm)
+        return bool(flag), np.float32(t.value), idx.value, np.array(list(nrm), dtype=np.float32)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().o_bvh_free(self.handle)
+            self.handle = None
+
+
+def fresh_states(nx, ny, window=None, seed=0):
+    """curand states of the pixels a (windowed) render touches: stream 0 plus the window's rows."""
+    L = lib()
+    r0, r1, c0, c1 = window if window is not None else (0, ny, 0, nx)
+    states = np.zeros(nx * ny, dtype=STATE_DTYPE)
+    L.o_set_curand_state_range(states.ctypes.data, 0, 1, seed)
+    for y in range(r0, r1):
+        first = y * nx + c0
+        L.o_set_curand_state_range(states[first:].ctypes.data, first, c1 - c0, seed)
+    return states
+
+
+def render_bvh(bvh, cam, nx, ny, samples, states, window=None, max_depth=8, frame=0):
+    """The render kernel with world = the BVH (renderBVHAnimation, core/render.h:222).  `states`
+    must be the array the BVH was built with (the build has advanced stream 0)."""
+    if window is None:
+        window = (0, ny, 0, nx)
+    r0, r1, c0, c1 = window
+    buf = np.zeros((ny, nx, 3), dtype=np.float32)
+    lib().o_render_window_bvh(_fp(buf), bvh.handle, C.byref(cam), states.ctypes.data,
+                              nx, ny, samples, max_depth, frame, r0, r1, c0, c1)
+    return buf, states
 
 
 def parse_obj(path):

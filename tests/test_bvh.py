@@ -1,0 +1,305 @@
+"""BVH world (hitable/bvh.h, core/aabb.h): CPU tests of the oracle restatement and of the host
+logic, GPU tests (marked) of the product against the oracle through the C ABI.
+
+PARITY UNPINNED at the thrust::sort boundary: the reference's comparator (BoxCompare, bvh.h:9-45)
+returns true on equal keys, so the order of a span is whatever Thrust's sequential merge sort does
+with it; the oracle and the product both restate that algorithm, independently (C and C++)."""
+import os
+
+import numpy as np
+import pytest
+
+from cudaraytracer_amd import _lib, api, scenes
+
+BVH_GOLDEN = {
+    "bvh_sphere1000_96x54x4": lambda: scenes.displaced_sphere(20, 25),
+    "bvh_soup96_48x48x4": lambda: scenes.random_soup(96, 7),
+    "bvh_cornell_100x75x8": scenes.cornell32,
+}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def oracle_scene(oracle, sc, nx, ny):
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    c = sc["camera"]
+    cam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny),
+                             c["aperture"], c["focus"])
+    return w, cam
+
+
+# ------------------------------------------------------------------ oracle (CPU)
+@pytest.mark.parametrize("name", sorted(BVH_GOLDEN))
+def test_oracle_bvh_matches_golden(oracle, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    nx, ny, spp = int(g["nx"]), int(g["ny"]), int(g["spp"])
+    w, cam = oracle_scene(oracle, BVH_GOLDEN[name](), nx, ny)
+    states = oracle.fresh_states(nx, ny)
+    bvh = oracle.Bvh(w, states)
+    nodes = bvh.nodes()
+    assert np.array_equal(bits(nodes["box"]), bits(g["boxes"]))
+    for k, f in [("skip", "skip"), ("first", "first"), ("count", "count"), ("is_leaf", "isLeaf"), ("depth", "depth"), ("axis", "axis")]:
+        assert np.array_equal(nodes[f], g[k]), k
+    assert np.array_equal(bvh.order(), g["order"])
+    buf, states = oracle.render_bvh(bvh, cam, nx, ny, spp, states)
+    assert np.array_equal(bits(buf), bits(g["rgb"]))
+
+
+def test_oracle_tree_shape(oracle):
+    """Median split n/2 | n - n/2, leaves of 1 or 2 triangles, every triangle in exactly one leaf,
+    one axis draw per node from stream 0, boxes contain their children."""
+    sc = scenes.displaced_sphere(12, 9)          # 216 triangles
+    w, _ = oracle_scene(oracle, sc, 8, 8)
+    states = oracle.fresh_states(8, 8)
+    s0 = states[0].copy()
+    bvh = oracle.Bvh(w, states)
+    nodes, order = bvh.nodes(), bvh.order()
+    assert sorted(order.tolist()) == list(range(216))
+    leaves = nodes[nodes["isLeaf"] == 1]
+    assert set(leaves["count"].tolist()) <= {1, 2} and leaves["count"].sum() == 216
+    assert nodes[0]["count"] == 216 and nodes[0]["skip"] == len(nodes)
+    for i, nd in enumerate(nodes):
+        if not nd["isLeaf"]:
+            l, r = nodes[nd["left"]], nodes[nd["right"]]
+            assert nd["left"] == i + 1 and nd["right"] == l["skip"]
+            assert l["count"] == nd["count"] // 2 and r["count"] == nd["count"] - nd["count"] // 2
+            assert (nd["box"][:3] <= np.minimum(l["box"][:3], r["box"][:3])).all()
+            assert (nd["box"][3:] >= np.maximum(l["box"][3:], r["box"][3:])).all()
+    # stream 0 advanced by exactly one draw per node
+    probe = np.zeros(1, dtype=oracle.STATE_DTYPE)
+    probe[0] = s0
+    import ctypes as C
+    st = oracle.CurandState.from_buffer(probe)
+    for _ in range(len(nodes)):
+        oracle.lib().o_curand(C.byref(st))
+    assert probe[0] == states[0]
+
+
+def test_oracle_bvh_semantics_differ_from_the_list_where_the_reference_does(oracle):
+    """(a) a triangle behind the eye: the list accepts its negative t (no range test,
+    triangle.h:92-99), the BVH never reaches it — AABB::hit starts from t_min = 0.001 (aabb.h:30-43).
+    (b) coincident duplicates in different leaves: the list keeps the lowest index (strict <), the
+    tree's merge `left.t < right.t ? left : right` keeps the right-hand leaf (bvh.h:172-179)."""
+    # tilted: an axis-aligned triangle has a flat box, which AABB::hit never reports (t_max <= t_min)
+    tri = np.array([[-1, -1, 0.25], [1, -1, 0], [0, 1, -0.25]], dtype=np.float32)
+    behind = tri + np.array([0, 0, 5], dtype=np.float32)
+    front = tri + np.array([0, 0, -5], dtype=np.float32)
+    far = tri * 3 + np.array([40, 0, -5], dtype=np.float32)
+    far2 = tri * 3 + np.array([-40, 0, -5], dtype=np.float32)
+
+    def world(tris):
+        pts = np.concatenate(tris).astype(np.float32)
+        idx = np.arange(len(pts), dtype=np.float32).reshape(-1, 3)
+        nrm = np.tile(np.array([[0, 0, -1]], dtype=np.float32), (len(idx), 1))
+        return oracle.World(pts, idx, nrm, 0)
+
+    flat = world([np.array([[-1, -1, -5], [1, -1, -5], [0, 1, -5]], dtype=np.float32)])
+    assert flat.hit((0.0, 0.0, 0.0), (0.0, 0.0, -1.0))[0]
+    assert not oracle.Bvh(flat, oracle.fresh_states(4, 4)).hit((0.0, 0.0, 0.0), (0.0, 0.0, -1.0))[0]   # flat box: never hit
+
+    org, d = (0.0, 0.0, 0.0), (0.0, 0.0, -1.0)
+    w = world([behind, far, far2])
+    f_list, t_list, i_list, _ = w.hit(org, d)
+    assert f_list and t_list < 0 and i_list == 0
+    states = oracle.fresh_states(4, 4)
+    f_bvh, _, _, _ = oracle.Bvh(w, states).hit(org, d)
+    assert not f_bvh
+    w = world([front, front, front, front, front])
+    assert w.hit(org, d)[2] == 0
+    bvh = oracle.Bvh(w, oracle.fresh_states(4, 4))
+    f, t, i, _ = bvh.hit(org, d)
+    order, nodes = bvh.order(), bvh.nodes()
+    last_leaf = nodes[nodes["isLeaf"] == 1][-1]
+    assert f and abs(t - 5.0) < 0.2 and i == order[last_leaf["first"]]      # last leaf, its first triangle
+
+
+# ------------------------------------------------------------------ host logic / ABI (CPU)
+def test_timing_csv_format(crt_built, tmp_path):
+    p = str(tmp_path / "output.csv")
+    api.writeCSV(p, [["frame", "rendering", "update", "build"], ["", "", "", "0.125"],
+                     ["0", "1.5", "0.25", ""], ["1", "2", "0.5", ""]])
+    assert open(p).read() == "frame,rendering,update,build\n,,,0.125000\n0,1.500000,0.250000,\n1,2.000000,0.500000,\n"
+    with pytest.raises(_lib.CrtError):
+        api.writeCSV(str(tmp_path / "no_such_dir" / "x.csv"), [["frame"], ["", "", "", "0"]])
+
+
+def test_bvh_entry_points_fail_loudly_without_device(crt_built):
+    if crt_built.crt_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    assert crt_built.crt_scene_build_bvh(None, None, 0) == _lib.CRT_ERR_INVALID
+    assert crt_built.crt_scene_refit_bvh(None, None) == _lib.CRT_ERR_INVALID
+    assert crt_built.crt_scene_bvh_node_count(None) == _lib.CRT_ERR_INVALID
+
+
+# ------------------------------------------------------------------ product vs oracle (GPU)
+def make(sc, nx, ny):
+    scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    c = sc["camera"]
+    return scene, api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+
+
+def hip_bvh_frames(gpu, scene, cam, nx, ny, spp, frames=1, variant=0, build=True, poses=None):
+    st = api.SetCurandState(nx, ny, 0)
+    if build:
+        api.create_BVHfromList(scene, st)
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    prev = _lib.lib().crt_set_kernel_variant(variant)
+    outs = []
+    try:
+        for f in range(frames):
+            if poses is not None and f > 0:
+                scene.update_pose(poses[f], stream=gpu.cuda.current_stream())
+                api.Update_BVH(scene, gpu.cuda.current_stream())
+            api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, frame_index=f, stream=gpu.cuda.current_stream(), bvh=True)
+            gpu.cuda.synchronize()
+            outs.append(d.cpu().numpy().reshape(ny, nx, 3).copy())
+    finally:
+        _lib.lib().crt_set_kernel_variant(prev)
+    return outs, st.export()
+
+
+def assert_same_tree(scene, bvh):
+    boxes, meta, slots = scene.bvh_export()
+    nodes = bvh.nodes()
+    assert len(boxes) == len(nodes)
+    assert np.array_equal(bits(boxes), bits(nodes["box"]))
+    assert np.array_equal(meta[:, 0], nodes["skip"]) and np.array_equal(meta[:, 3], nodes["depth"])
+    leaf = nodes["isLeaf"] == 1
+    assert np.array_equal(meta[:, 2], np.where(leaf, nodes["count"], 0))
+    assert np.array_equal(meta[leaf, 1], nodes["first"][leaf])
+    assert np.array_equal(slots, bvh.order())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 5, 6])
+@pytest.mark.parametrize("name", sorted(BVH_GOLDEN))
+def test_gpu_bvh_matches_golden(gpu, golden_dir, name, variant):
+    """Tree (boxes, structure, leaf order) and frame equal the oracle's, in the hot traversal loop
+    and in both forced general modes; stream 0 is left where the reference leaves it."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    nx, ny, spp = int(g["nx"]), int(g["ny"]), int(g["spp"])
+    scene, cam = make(BVH_GOLDEN[name](), nx, ny)
+    (rgb,), states = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
+    boxes, meta, slots = scene.bvh_export()
+    assert np.array_equal(bits(boxes), bits(g["boxes"]))
+    assert np.array_equal(meta[:, 0], g["skip"]) and np.array_equal(meta[:, 3], g["depth"])
+    assert np.array_equal(slots, g["order"])
+    assert np.array_equal(bits(rgb), bits(g["rgb"])), "max |diff| %g" % np.nanmax(np.abs(rgb - g["rgb"]))
+    assert np.array_equal(states[1:2048], g["states_after"][1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,ntri,nx,ny,spp", [(1, 64, 40, 24, 3), (2, 200, 33, 17, 2), (3, 17, 16, 16, 8), (4, 500, 64, 40, 2),
+                                                   (5, 1, 16, 16, 2), (6, 2, 16, 16, 2), (7, 3, 16, 16, 2)])
+def test_gpu_bvh_random_soup_matches_oracle(gpu, oracle, seed, ntri, nx, ny, spp):
+    """Adversarial soups: triangles behind and through the eye, duplicates, degenerate triangles
+    (NaN normals), 1-, 2- and 3-triangle lists."""
+    sc = scenes.random_soup(ntri, seed)
+    scene, cam = make(sc, nx, ny)
+    w, ocam = oracle_scene(oracle, sc, nx, ny)
+    states = oracle.fresh_states(nx, ny)
+    bvh = oracle.Bvh(w, states)
+    ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
+    for variant in (0, 5, 6):
+        (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
+        assert_same_tree(scene, bvh)
+        assert np.array_equal(bits(rgb), bits(ref)), variant
+        after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+        assert np.array_equal(st[1:], after[1:])
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_unbounded_scene_takes_the_ieee_loop(gpu, oracle):
+    """Coordinates beyond 2^38 and tiny nonzero coordinates: the host selects the literal-division
+    kernel; same pixels as the oracle."""
+    for scale, shift in [(1.0e13, 0.0), (1.0e-19, 0.0)]:
+        sc = scenes.random_soup(40, 21)
+        sc["points"] = (sc["points"] * np.float32(scale)).astype(np.float32)
+        nx, ny, spp = 24, 16, 2
+        scene, cam = make(sc, nx, ny)
+        w, ocam = oracle_scene(oracle, sc, nx, ny)
+        states = oracle.fresh_states(nx, ny)
+        bvh = oracle.Bvh(w, states)
+        ref, _ = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
+        (rgb,), _ = hip_bvh_frames(gpu, scene, cam, nx, ny, spp)
+        assert np.array_equal(bits(rgb), bits(ref)), scale
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_refit_and_frame_loop(gpu, oracle):
+    """renderBVHAnimation (core/render.h:191-237): per frame update_pose, Update_BVH (refit), render;
+    the RNG streams continue.  Boxes after the refit equal BVHNode::UpdateBVH's, frames equal the oracle's."""
+    sc = scenes.displaced_sphere(16, 20)
+    nx, ny, spp = 64, 40, 2
+    scene, cam = make(sc, nx, ny)
+    w, ocam = oracle_scene(oracle, sc, nx, ny)
+    pts0 = sc["points"]
+    poses = [pts0, (pts0 * np.float32(1.15) + np.float32(3.0)).astype(np.float32),
+             (pts0 * np.array([0.8, 1.2, 1.0], dtype=np.float32)).astype(np.float32)]
+    states = oracle.fresh_states(nx, ny)
+    bvh = oracle.Bvh(w, states)
+    refs = []
+    for f in range(3):
+        if f > 0:
+            w.update_pose(poses[f])
+            bvh.update()
+        r, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states, frame=f)
+        refs.append(r)
+    outs, _ = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, frames=3, poses=poses)
+    assert_same_tree(scene, bvh)                                  # after two refits
+    for f in range(3):
+        skip = 0 if f == 0 else 1                                 # pixel 0 of later frames: state[0] race
+        assert np.array_equal(bits(outs[f]).reshape(-1, 3)[skip:], bits(refs[f]).reshape(-1, 3)[skip:]), f
+    # the Python mirror of the reference's driver, with its timing rows
+    scene2, _ = make(sc, nx, ny)
+    st = api.SetCurandState(nx, ny, 0)
+    data = [["frame", "rendering", "update", "build"]]
+    frames = api.renderBVH(nx, ny, spp, 8, 0, 2, scene2, cam, st, data, write_png=False, poses=poses)
+    assert len(data) == 5 and data[1][:3] == ["", "", ""] and data[2][0] == "0" and data[4][3] == ""
+    assert np.array_equal(bits(frames[0]), bits(refs[0]))
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_strips_and_list_agreement_on_the_bench_mesh(gpu, oracle, tmp_path):
+    """The C3 mesh (100 000 triangles) at 1920x1080 x 2 spp through the BVH world: equals the list
+    world wherever the two semantics agree (a closed mesh seen from outside: everywhere but pixel 0,
+    whose stream the build advanced), the 8 strip sets equal the full frame, and an oracle crop on
+    the silhouette matches."""
+    path, nx, ny, _ = scenes.baseline_obj("C3", str(tmp_path))
+    spp = 2
+    scene = api.Scene.from_obj(path, scale=1.0)
+    cam = api.init_camera(nx, ny)
+    (rgb,), st_bvh = hip_bvh_frames(gpu, scene, cam, nx, ny, spp)
+    st = api.SetCurandState(nx, ny, 0)
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=gpu.cuda.current_stream())
+    gpu.cuda.synchronize()
+    lst = d.cpu().numpy().reshape(ny, nx, 3)
+    assert np.array_equal(bits(rgb).reshape(-1, 3)[1:], bits(lst).reshape(-1, 3)[1:])
+    from cudaraytracer_amd.dist import partition_strips
+    for r in (0, 5):
+        strips = partition_strips(ny, 8, r)
+        rows = sum(c for _, c in strips)
+        s = api.CurandState.for_strips(nx, ny, r, 32, 8, 0)
+        p = gpu.zeros(rows * nx * 3, dtype=gpu.float32, device="cuda")
+        api.render_strips(scene, cam, s, nx, ny, spp, r, 32, 8, p, stream=gpu.cuda.current_stream(), bvh=True)
+        gpu.cuda.synchronize()
+        got = p.cpu().numpy().reshape(rows, nx, 3)
+        want = np.concatenate([rgb[y0:y0 + c] for y0, c in strips], axis=0)
+        skip = 1 if r == 0 else 0            # rank 0's strips start at pixel 0, whose fresh stream was not advanced by a build
+        assert np.array_equal(bits(got).reshape(-1, 3)[skip:], bits(want).reshape(-1, 3)[skip:]), r
+    pts, idx = oracle.parse_obj(path)
+    w = oracle.World(pts, idx, None, 1)
+    ocam = oracle.make_camera((0, 100, 1000), (0, 150, 0), (0, 1, 0), 40.0, np.float32(nx) / np.float32(ny), 0.0, 10.0)
+    hit = (rgb[..., 0] - rgb[..., 2]) > 0.05
+    rows_hit = np.where(hit.any(axis=1))[0]
+    r_mid = int((rows_hit[0] + rows_hit[-1]) // 2)
+    c_edge = int(np.where(hit[r_mid])[0][0])
+    win = (r_mid, r_mid + 16, c_edge - 32, c_edge + 32)
+    states = oracle.fresh_states(nx, ny, window=win)
+    bvh = oracle.Bvh(w, states)
+    ref, _ = oracle.render_bvh(bvh, ocam, nx, ny, spp, states, window=win)
+    r0, r1, c0, c1 = win
+    assert np.array_equal(bits(rgb[r0:r1, c0:c1]), bits(ref[r0:r1, c0:c1]))

@@ -78,6 +78,32 @@ def main():
         print(name, buf.shape, "hit-rays %d/%d" % (int(sum(h[0] for h in hits)), len(hits)))
 
 
+BVH_RENDERS = [
+    ("bvh_sphere1000_96x54x4", lambda: scenes.displaced_sphere(20, 25), 96, 54, 4),
+    ("bvh_soup96_48x48x4", lambda: scenes.random_soup(96, 7), 48, 48, 4),
+    ("bvh_cornell_100x75x8", scenes.cornell32, 100, 75, 8),
+]
+
+
+def bvh_goldens():
+    """The BVH world (hitable/bvh.h): tree (boxes, structure, leaf order) + frame, built right after
+    SetCurandState like the reference's main() (kernel.cu:69-71,97): the build advances stream 0."""
+    for name, factory, nx, ny, spp in BVH_RENDERS:
+        sc = factory()
+        w = po.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        cam = camera_of(sc, nx, ny)
+        states = po.fresh_states(nx, ny)
+        bvh = po.Bvh(w, states)
+        nodes = bvh.nodes()
+        buf, states = po.render_bvh(bvh, cam, nx, ny, spp, states)
+        after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), rgb=buf, camera=po.camera_as_array(cam),
+                            boxes=nodes["box"], skip=nodes["skip"], first=nodes["first"], count=nodes["count"],
+                            is_leaf=nodes["isLeaf"], depth=nodes["depth"], axis=nodes["axis"], order=bvh.order(),
+                            states_after=after[:2048], nx=nx, ny=ny, spp=spp)
+        print(name, buf.shape, "nodes %d depth %d" % (len(nodes), nodes["depth"].max()))
+
+
 def small_bunny():
     """SURVEY §8c golden (4): the only real mesh the reference ships for this path,
     CudaTest/objects/small_bunny.obj (2503 v / 4968 f, plain `f a b c`), read by the oracle's
@@ -110,4 +136,5 @@ def small_bunny():
 
 if __name__ == "__main__":
     small_bunny()
+    bvh_goldens()
     main()
