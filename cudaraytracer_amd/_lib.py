@@ -22,6 +22,11 @@ class CrtError(RuntimeError):
         self.code = code
 
 
+class CrtMaterial(C.Structure):
+    """struct crt_material (include/crt.h)."""
+    _fields_ = [("kind", C.c_int), ("albedo", C.c_float * 3), ("param", C.c_float)]
+
+
 class CrtCamera(C.Structure):
     """struct crt_camera (include/crt.h) == Camera's data members, core/camera.h:46-52."""
     _fields_ = [(n, C.c_float * 3) for n in
@@ -67,6 +72,9 @@ PROTOTYPES = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "crt_render_strips": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "crt_scene_set_materials": (C.c_int, [C.c_void_p, C.POINTER(CrtMaterial), C.c_int, C.POINTER(C.c_int)]),
+    "crt_render_rows_ex": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "crt_scene_build_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "crt_scene_refit_bvh": (C.c_int, [C.c_void_p, C.c_void_p]),
     "crt_scene_bvh_node_count": (C.c_int, [C.c_void_p]),
@@ -113,6 +121,15 @@ def lib():
             raise CrtError(CRT_ERR_NO_DEVICE,
                            "libcrt_hip.so is not built (run __graft_entry__.build() or "
                            "`make -C cudaraytracer_amd/csrc`); there is no CPU fallback")
+        # torch bundles its own libamdhip64.so / libhsa-runtime64.so and asks for them by file name,
+        # libcrt_hip.so asks for libamdhip64.so.7 (SONAME).  If this library came first the loader
+        # would give torch a SECOND copy of the HIP runtime, and two runtimes in one process cannot
+        # both own the device (torch.cuda.is_available() turns False).  With torch's copy loaded
+        # first, the SONAME matches and both share it.  (C/C++ callers have no torch and no issue.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         h = C.CDLL(_LIB)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(h, name)

@@ -20,7 +20,11 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import CrtCamera, CrtError, check, check_handle
+from ._lib import CrtCamera, CrtError, CrtMaterial, check, check_handle
+
+LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = 0, 1, 2, 3       # crt_material.kind (material/material.h:57-161)
+WORLD_LIST, WORLD_BVH = 0, 1                                    # core/render.h:179 / :222
+SHADER_LAMBERT, SHADER_SHADE, SHADER_NORMAL = 0, 1, 2          # core/render.h:119-121
 
 DEFAULT_ALBEDO = (0.65, 0.05, 0.05)     # createScene.h:180
 
@@ -92,6 +96,22 @@ class Scene:
         pts = np.ascontiguousarray(new_points, dtype=np.float32).reshape(-1, 3)
         st = C.c_void_p(stream.cuda_stream) if stream is not None else None
         check(_lib.lib().crt_scene_update_pose(self.handle, _fp(pts), len(pts), st))
+
+    def set_materials(self, table, triangle_material=None):
+        """crt_scene_set_materials.  table: [(kind, (r, g, b), param), ...]; triangle_material: one
+        table index per triangle (None = all 0)."""
+        arr = (CrtMaterial * len(table))()
+        for k, (kind, albedo, param) in enumerate(table):
+            arr[k].kind = int(kind)
+            arr[k].albedo = (C.c_float * 3)(*[float(x) for x in albedo])
+            arr[k].param = float(param)
+        of = None
+        if triangle_material is not None:
+            tm = np.ascontiguousarray(triangle_material, dtype=np.int32)
+            if len(tm) != self.n_triangles:
+                raise CrtError(_lib.CRT_ERR_INVALID, "one material index per triangle is required")
+            of = tm.ctypes.data_as(C.POINTER(C.c_int))
+        check(_lib.lib().crt_scene_set_materials(self.handle, arr, len(table), of))
 
     def build_bvh(self, curand_state=None, seed=0):
         """crt_scene_build_bvh: BVHNode over the list (hitable/bvh.h:76-125).  curand_state: the states
@@ -202,6 +222,19 @@ def render_rows(scene, camera, curand_state, nx, ny, samples, row_begin, row_cou
     check(fn(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny,
                                      samples, max_depth, frame_index, row_begin, row_count,
                                      C.c_void_p(ptr), C.c_void_p(sptr)))
+
+
+def render_rows_ex(scene, camera, curand_state, nx, ny, samples, row_begin, row_count, d_rgb, world=WORLD_LIST,
+                   shader=SHADER_LAMBERT, max_depth=8, frame_index=0, stream=None):
+    """crt_render_rows_ex: the render kernel with an explicit world (list / BVH) and shader
+    (LambertShade / shade / shade_normal: the call at core/render.h:119-121)."""
+    ptr = d_rgb if isinstance(d_rgb, int) else d_rgb.data_ptr()
+    sptr = None
+    if stream is not None:
+        sptr = stream if isinstance(stream, int) else stream.cuda_stream
+    check(_lib.lib().crt_render_rows_ex(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny, samples, max_depth,
+                                        frame_index, row_begin, row_count, int(world), int(shader), C.c_void_p(ptr),
+                                        C.c_void_p(sptr)))
 
 
 def strip_rows(ny, first_strip, strip_rows_, strip_step):

@@ -242,9 +242,30 @@ const std::vector<uint32_t>& jump_table() {
     return table;
 }
 
+void rotation_zero_matrix(float m[9]) {   // rotate(., vec3(0)) as a matrix: rows of vec3.h:200-213 with sin/cos of 0
+    const float radiansX = (float)((M_PI / 180.) * 0.0f), sin_X = sinf(radiansX), cos_X = cosf(radiansX);
+    const float radiansY = (float)((M_PI / 180.) * 0.0f), sin_Y = sinf(radiansY), cos_Y = cosf(radiansY);
+    const float radiansZ = (float)(-(M_PI / 180.) * 0.0f), sin_Z = sinf(radiansZ), cos_Z = cosf(radiansZ);
+    m[0] = cos_Y * cos_Z; m[1] = -cos_Y * sin_Z; m[2] = sin_Y;
+    m[3] = sin_X * sin_Y * cos_Z + cos_X * sin_Z; m[4] = -sin_X * sin_Y * sin_Z + cos_X * cos_Z; m[5] = -sin_X * cos_Y;
+    m[6] = -cos_X * sin_Y * cos_Z + sin_X * sin_Z; m[7] = cos_X * sin_Y * sin_Z + sin_X * cos_Z; m[8] = cos_X * cos_Y;
+}
+
 }  // namespace crt_host
 
 using namespace crt_host;
+
+int upload_bvh_materials(crt_scene* s) {
+    if (!s->bvh) return CRT_OK;
+    crt_bvh* t = s->bvh;
+    if (t->d_material_slots) { (void)hipFree(t->d_material_slots); t->d_material_slots = nullptr; }
+    if (s->h_material_of.empty()) return CRT_OK;
+    std::vector<int> slots((size_t)s->n_tris);
+    for (int k = 0; k < s->n_tris; ++k) slots[k] = s->h_material_of[t->slot_tri[k]];
+    HIP_TRY(hipMalloc(&t->d_material_slots, slots.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(t->d_material_slots, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    return CRT_OK;
+}
 
 extern "C" {
 
@@ -348,6 +369,13 @@ crt_scene* crt_scene_from_mesh(const float* points, int n_points, const float* i
     s->n_points = n_points;
     s->h_base = base;
     s->h_idx = idx0;
+    crt_material lam;
+    lam.kind = CRT_LAMBERTIAN;
+    memcpy(lam.albedo, albedo, sizeof lam.albedo);
+    lam.param = 0.0f;
+    s->h_materials.assign(1, lam);   // new Lambertian(new ConstantTexture(albedo)), createScene.h:180
+    if (e == hipSuccess) e = hipMalloc(&s->d_materials, sizeof(crt_material));
+    if (e == hipSuccess) e = hipMemcpy(s->d_materials, &lam, sizeof lam, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&s->d_idx, nalloc * 3 * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(s->d_idx, idx0.data(), nalloc * 3 * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_base, base.data(), nalloc * crt::kBaseFloats * sizeof(float), hipMemcpyHostToDevice);
@@ -483,6 +511,8 @@ void crt_scene_free(crt_scene* s) {
     if (s->d_points) (void)hipFree(s->d_points);
     if (s->h_points) (void)hipHostFree(s->h_points);
     if (s->pose_copied) (void)hipEventDestroy(s->pose_copied);
+    if (s->d_materials) (void)hipFree(s->d_materials);
+    if (s->d_material_of) (void)hipFree(s->d_material_of);
     delete s->bvh;
     delete s;
 }
@@ -582,7 +612,8 @@ int crt_set_kernel_variant(int variant) {
 namespace {
 // world: 0 = the triangle list (renderListAnimation, render.h:179), 1 = the BVH over it (renderBVHAnimation, render.h:222)
 int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny, int samples,
-                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_, int world = 0);
+                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_, int world = 0,
+                int shader = 0, int max_depth = 0);
 }
 
 int crt_render_rows(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
@@ -633,6 +664,62 @@ int crt_render_strips_bvh(const crt_scene* scene, const crt_camera* camera, crt_
                        strip_row_count(ny, row_begin, strip_rows, strip_step), strip_rows, strip_step, d_rgb, stream_, 1);
 }
 
+int crt_render_rows_ex(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
+                       int samples, int max_depth, int frame_index, int row_begin, int row_count,
+                       int world, int shader, float* d_rgb, void* stream_) {
+    (void)frame_index;
+    if (nx <= 0 || ny <= 0 || samples < 0 || row_begin < 0 || row_count <= 0 || row_begin + row_count > ny)
+        return fail(CRT_ERR_INVALID, "crt_render_rows_ex: bad image/row range (nx=%d ny=%d rows %d+%d)", nx, ny, row_begin, row_count);
+    if ((world != CRT_WORLD_LIST && world != CRT_WORLD_BVH) || shader < CRT_SHADER_LAMBERT || shader > CRT_SHADER_NORMAL)
+        return fail(CRT_ERR_INVALID, "crt_render_rows_ex: world %d / shader %d", world, shader);
+    if (shader == CRT_SHADER_SHADE && (max_depth < 0 || max_depth > crt::kMaxShadeDepth))
+        return fail(CRT_ERR_UNSUPPORTED, "crt_render_rows_ex: max_depth %d (0..%d)", max_depth, crt::kMaxShadeDepth);
+    return render_impl(scene, camera, rng, nx, ny, samples, row_begin, row_count, 32, 1, d_rgb, stream_, world, shader, max_depth);
+}
+
+int crt_scene_set_materials(crt_scene* s, const crt_material* table, int n_materials, const int* triangle_material) {
+    if (!s || !table || n_materials < 1) return fail(CRT_ERR_INVALID, "crt_scene_set_materials: null or empty table");
+    for (int k = 0; k < n_materials; ++k)
+        if (table[k].kind < CRT_LAMBERTIAN || table[k].kind > CRT_DIFFUSE_LIGHT)
+            return fail(CRT_ERR_INVALID, "crt_scene_set_materials: material %d has kind %d", k, table[k].kind);
+    if (triangle_material)
+        for (int i = 0; i < s->n_tris; ++i)
+            if (triangle_material[i] < 0 || triangle_material[i] >= n_materials)
+                return fail(CRT_ERR_INVALID, "crt_scene_set_materials: triangle %d uses material %d of %d", i, triangle_material[i], n_materials);
+    if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_scene_set_materials: no HIP device");
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    if (device != s->device)
+        return fail(CRT_ERR_INVALID, "crt_scene_set_materials: current device is %d, the scene lives on device %d", device, s->device);
+    HIP_TRY(hipDeviceSynchronize());   // renders in flight still read the old table
+    void* d_tab = nullptr;
+    int* d_of = nullptr;
+    HIP_TRY(hipMalloc(&d_tab, (size_t)n_materials * sizeof(crt_material)));
+    hipError_t e = hipMemcpy(d_tab, table, (size_t)n_materials * sizeof(crt_material), hipMemcpyHostToDevice);
+    if (e == hipSuccess && triangle_material && s->n_tris > 0) {
+        e = hipMalloc(&d_of, (size_t)s->n_tris * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(d_of, triangle_material, (size_t)s->n_tris * sizeof(int), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(d_tab);
+        if (d_of) (void)hipFree(d_of);
+        return fail(CRT_ERR_HIP, "crt_scene_set_materials: %s", hipGetErrorString(e));
+    }
+    if (s->d_materials) (void)hipFree(s->d_materials);
+    if (s->d_material_of) (void)hipFree(s->d_material_of);
+    s->d_materials = d_tab;
+    s->d_material_of = d_of;
+    s->h_materials.assign(table, table + n_materials);
+    s->h_material_of.clear();
+    if (triangle_material) s->h_material_of.assign(triangle_material, triangle_material + s->n_tris);
+    // the specialised LambertShade kernels assume ONE Lambertian; its colour is the scene's albedo
+    bool one = table[0].kind == CRT_LAMBERTIAN;
+    for (int i = 0; one && triangle_material && i < s->n_tris; ++i) one = triangle_material[i] == 0;
+    s->single_lambertian = one;
+    if (one) memcpy(s->albedo, table[0].albedo, sizeof s->albedo);
+    return upload_bvh_materials(s);
+}
+
 int crt_strip_rows(int ny, int first_strip, int strip_rows, int strip_step) {
     if (ny <= 0 || first_strip < 0 || strip_rows <= 0 || strip_step <= 0) return CRT_ERR_INVALID;
     return strip_row_count(ny, first_strip * strip_rows, strip_rows, strip_step);
@@ -640,8 +727,10 @@ int crt_strip_rows(int ny, int first_strip, int strip_rows, int strip_step) {
 
 namespace {
 int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny, int samples,
-                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_, int world) {
+                int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_, int world,
+                int shader, int max_depth) {
     if (!scene || !camera || !rng || !d_rgb) return fail(CRT_ERR_INVALID, "crt_render_rows: null argument");
+    const bool generic = shader != CRT_SHADER_LAMBERT || !scene->single_lambertian;
     if (world == 1 && !scene->bvh) return fail(CRT_ERR_INVALID, "crt_render_rows_bvh: the scene has no BVH (crt_scene_build_bvh)");
     if ((long long)nx * ny > 0x7fffffffLL)
         return fail(CRT_ERR_INVALID, "crt_render_rows: nx*ny exceeds the reference's int pixel_index (core/render.h:111)");
@@ -677,6 +766,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         HIP_TRY(hipEventCreate(&cx.ev_mid));
     }
     HIP_TRY(hipEventRecord(cx.ev_start, stream));   // the per-frame prepasses count as binning time
+    if (!generic)
     HIP_TRY(crt::launch_tri_prepass(world == 1 ? scene->bvh->d_base_slots : scene->d_base, scene->n_tris, camera->origin,
                                     cx.d_rec, stream));
 
@@ -710,6 +800,27 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     p.rny = 1.0f / (float)ny;
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
 
+    if (generic) {
+        // any shader, any materials (crt_shade_kernels.hpp); fast arithmetic under the same conditions as below
+        bool fast = scene->tiled_safe && (world == 0 || scene->bvh->coords_not_tiny);
+        for (int k = 0; k < 3; ++k) {
+            const float o = camera->origin[k];
+            fast = fast && std::isfinite(o) && fabsf(o) <= 274877906944.0f && (o == 0.0f || fabsf(o) >= 1.3877787807814457e-17f);
+            fast = fast && std::isfinite(camera->lower_left_corner[k]) && std::isfinite(camera->horizontal[k]) && std::isfinite(camera->vertical[k]);
+        }
+        const int force_mode = g_variant == 5 ? 1 : (g_variant == 6 ? 2 : 0);
+        float rot[9];
+        rotation_zero_matrix(rot);
+        const crt_bvh* t = world == 1 ? scene->bvh : nullptr;
+        HIP_TRY(crt::launch_render_generic(p, t ? t->d_base_slots : scene->d_base, t ? t->d_shade_n_slots : scene->d_shade_n,
+                                           t ? t->d_material_slots : scene->d_material_of, scene->d_materials, scene->n_tris,
+                                           t ? t->d_nodes : nullptr, t ? t->n_nodes : 0, rot, rng->d_state, d_rgb, world == 1, fast,
+                                           shader, max_depth, force_mode, stream));
+        cx.ev_has_mid = false;
+        HIP_TRY(hipEventRecord(cx.ev_stop, stream));
+        cx.ev_valid = true;
+        return CRT_OK;
+    }
     if (world == 1) {
         // fast arithmetic of the traversal: bounded scene and origin, no nonzero coordinate below 2^-56
         // (crt_bvh_kernels.hpp: box_hit_fast); otherwise the literal IEEE loop

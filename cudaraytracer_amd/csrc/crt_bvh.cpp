@@ -53,16 +53,7 @@ float xw_uniform(HostXorwow& s) {             // curand_uniform: x * 2^-32 + 2^-
     return (float)x * k + (k / 2.0f);
 }
 
-// ---- rotate(., vec3(0)) as a matrix: the reference evaluates sin/cos of 0 and builds the rows
-// (vec3.h:200-213); the entries are 1, +0 and -0.
-void rotation_zero_matrix(float m[9]) {
-    const float radiansX = (float)((M_PI / 180.) * 0.0f), sin_X = sinf(radiansX), cos_X = cosf(radiansX);
-    const float radiansY = (float)((M_PI / 180.) * 0.0f), sin_Y = sinf(radiansY), cos_Y = cosf(radiansY);
-    const float radiansZ = (float)(-(M_PI / 180.) * 0.0f), sin_Z = sinf(radiansZ), cos_Z = cosf(radiansZ);
-    m[0] = cos_Y * cos_Z; m[1] = -cos_Y * sin_Z; m[2] = sin_Y;
-    m[3] = sin_X * sin_Y * cos_Z + cos_X * sin_Z; m[4] = -sin_X * sin_Y * sin_Z + cos_X * cos_Z; m[5] = -sin_X * cos_Y;
-    m[6] = -cos_X * sin_Y * cos_Z + sin_X * sin_Z; m[7] = cos_X * sin_Y * sin_Z + sin_X * cos_Z; m[8] = cos_X * cos_Y;
-}
+// ---- rotate(., vec3(0)) as a matrix (crt_host::rotation_zero_matrix): the entries are 1, +0 and -0.
 H3 rot_apply(const float* m, H3 v) {          // vec3.h:215: (origin * rotate_k).sum()
     return H3{(v.x * m[0] + v.y * m[1]) + v.z * m[2], (v.x * m[3] + v.y * m[4]) + v.z * m[5],
               (v.x * m[6] + v.y * m[7]) + v.z * m[8]};
@@ -187,6 +178,7 @@ crt_bvh::~crt_bvh() {
     if (d_shade_n_slots) (void)hipFree(d_shade_n_slots);
     if (d_idx_slots) (void)hipFree(d_idx_slots);
     if (d_level_nodes) (void)hipFree(d_level_nodes);
+    if (d_material_slots) (void)hipFree(d_material_slots);
 }
 
 extern "C" {
@@ -296,7 +288,7 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
     }
     delete s->bvh;
     s->bvh = t;
-    return CRT_OK;
+    return upload_bvh_materials(s);
 }
 
 int crt_scene_refit_bvh(crt_scene* s, void* stream_) {

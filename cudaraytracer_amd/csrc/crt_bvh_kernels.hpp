@@ -96,9 +96,38 @@ __device__ __forceinline__ bool box_hit_fast(float4 n0, float4 n1, V3 o, V3 d, V
     return !(t_max <= t_min);
 }
 
-// Triangle::collision_detection (shapes/triangle.h:57-100) on one slot's exact record, per lane.
+// Triangle::collision_detection (shapes/triangle.h:57-100) for an arbitrary ray origin, from the base
+// record (v0 v1 v2 n): secondary rays (crt_shade_kernels.hpp) do not start at the camera, so the
+// per-frame exact records do not apply.
 template <bool FAST>
-__device__ __forceinline__ bool tri_hit_lane(const float* __restrict__ rec, int slot, V3 d, float& t_out) {
+__device__ __forceinline__ bool tri_hit_base(const float* __restrict__ b, V3 o, V3 d, float& t_out) {
+    if (d.x * b[9] + d.y * b[10] + d.z * b[11] < 0.0f) return false;          // triangle.h:61
+    const float e1x = b[3] - b[0], e1y = b[4] - b[1], e1z = b[5] - b[2];      // triangle.h:69
+    const float e2x = b[6] - b[0], e2y = b[7] - b[1], e2z = b[8] - b[2];      // triangle.h:70
+    const float hx = (d.y * e2z - d.z * e2y);                                 // triangle.h:71-72
+    const float hy = (-(d.x * e2z - d.z * e2x));
+    const float hz = (d.x * e2y - d.y * e2x);
+    const float a = e1x * hx + e1y * hy + e1z * hz;
+    if (a > -kTriEpsilon && a < kTriEpsilon) return false;                    // triangle.h:77
+    const float f = FAST ? ((fabsf(a) >= 7.888609052210118e-31f && fabsf(a) <= 1.2676506002282294e30f) ? reciprocal<true>(a) : 1.0f / a)
+                         : 1.0f / a;                                          // triangle.h:80 (fast form valid for 2^-100..2^100)
+    const float sx = o.x - b[0], sy = o.y - b[1], sz = o.z - b[2];            // triangle.h:81
+    const float u = f * (sx * hx + sy * hy + sz * hz);                        // triangle.h:82
+    if (u < 0.0f || u > 1.0f) return false;                                   // triangle.h:84
+    const float qx = (sy * e1z - sz * e1y);                                   // triangle.h:87
+    const float qy = (-(sx * e1z - sz * e1x));
+    const float qz = (sx * e1y - sy * e1x);
+    const float v = f * (d.x * qx + d.y * qy + d.z * qz);                     // triangle.h:88
+    if (v < 0.0f || u + v > 1.0f) return false;                               // triangle.h:89
+    t_out = f * (e2x * qx + e2y * qy + e2z * qz);                             // triangle.h:92
+    return true;
+}
+
+// Triangle::collision_detection (shapes/triangle.h:57-100) on one slot's exact record, per lane
+// (PRIMARY: the ray starts at the camera origin the records were derived for; else from the base record).
+template <bool FAST, bool PRIMARY = true>
+__device__ __forceinline__ bool tri_hit_lane(const float* __restrict__ rec, int slot, V3 o, V3 d, float& t_out) {
+    if (!PRIMARY) return tri_hit_base<FAST>(rec + (size_t)slot * kBaseFloats, o, d, t_out);
     const float4* r = reinterpret_cast<const float4*>(rec + (size_t)slot * kRecFloats);
     const float4 ra = r[0], rb = r[1], rc = r[2], rd = r[3];   // n.xyz e2.x | e2.yz e1.xy | e1.z s.xyz | q.xyz tq
     if (d.x * ra.x + d.y * ra.y + d.z * ra.z < 0.0f) return false;            // triangle.h:61
@@ -119,13 +148,13 @@ __device__ __forceinline__ bool tri_hit_lane(const float* __restrict__ rec, int 
 
 // A leaf's HitableList (1 or 2 triangles, hitable_list.h:76-91: strict <, t_max = FLT_MAX) folded
 // into the running result with the tree's merge rule (bvh.h:172-179).
-template <bool FAST>
-__device__ __forceinline__ void leaf_hit(const float* __restrict__ rec, int first, int count, V3 d, float& best_t, int& best_slot) {
+template <bool FAST, bool PRIMARY = true>
+__device__ __forceinline__ void leaf_hit(const float* __restrict__ rec, int first, int count, V3 o, V3 d, float& best_t, int& best_slot) {
     float closest = FLT_MAX;
     int slot = -1;
     for (int j = 0; j < count; ++j) {
         float t;
-        if (tri_hit_lane<FAST>(rec, first + j, d, t) && t < closest) {
+        if (tri_hit_lane<FAST, PRIMARY>(rec, first + j, o, d, t) && t < closest) {
             closest = t;
             slot = first + j;
         }
@@ -137,6 +166,7 @@ __device__ __forceinline__ void leaf_hit(const float* __restrict__ rec, int firs
 }
 
 // Hot loop: every lane of the wavefront has c4 == c3 and ordinary components.
+template <bool PRIMARY = true>
 __device__ __forceinline__ void bvh_walk_fast(const BvhView& b, const float* __restrict__ rec, V3 o, V3 c1, V3 c2, V3 c3,
                                               float& best_t, int& best_slot) {
     const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
@@ -151,7 +181,7 @@ __device__ __forceinline__ void bvh_walk_fast(const BvhView& b, const float* __r
             y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
         }
         const bool hit = box_hit_fast(n0, n1, o, d, y);
-        if (hit && count != 0) leaf_hit<true>(rec, first, count, c3, best_t, best_slot);   // triangles see F^(depth+3) = c3
+        if (hit && count != 0) leaf_hit<true, PRIMARY>(rec, first, count, o, c3, best_t, best_slot);   // triangles see F^(depth+3) = c3
         i = (hit && count == 0) ? i + 1 : skip;
     }
 }
@@ -171,26 +201,34 @@ __device__ __forceinline__ V3 chain_at(const float* m, int k, V3 c1, V3 c2, V3 c
     return c;
 }
 
-template <bool FAST>
+// dir_used: the direction the winning triangle was tested with (rec.p = o + t * that, triangle.h:95).
+template <bool FAST, bool PRIMARY = true>
 __device__ __forceinline__ void bvh_walk_general(const BvhView& b, const float* __restrict__ rec, V3 o, V3 c1, V3 c2, V3 c3,
-                                                 V3 c4, int mode, float& best_t, int& best_slot) {
+                                                 V3 c4, int mode, float& best_t, int& best_slot, V3& dir_used) {
     int i = 0;
     while (i < b.n_nodes) {
         const float4 n0 = b.nodes[2 * (size_t)i], n1 = b.nodes[2 * (size_t)i + 1];
         const int skip = __float_as_int(n1.z), info = __float_as_int(n1.w);
         const int depth = (info >> 26) & 31, count = (info >> 24) & 3, first = info & 0xffffff;
         const bool hit = box_hit_ieee(n0, n1, o, chain_at<FAST>(b.rot, depth + 1, c1, c2, c3, c4, mode));
-        if (hit && count != 0)
-            leaf_hit<FAST>(rec, first, count, chain_at<FAST>(b.rot, depth + 3, c1, c2, c3, c4, mode), best_t, best_slot);
+        if (hit && count != 0) {
+            const V3 dt = chain_at<FAST>(b.rot, depth + 3, c1, c2, c3, c4, mode);
+            const int before = best_slot;
+            const float t_before = best_t;
+            leaf_hit<FAST, PRIMARY>(rec, first, count, o, dt, best_t, best_slot);
+            if (best_slot != before || __float_as_uint(best_t) != __float_as_uint(t_before)) dir_used = dt;
+        }
         i = (hit && count == 0) ? i + 1 : skip;
     }
 }
 
 // (*world)->hit(r, 0.001, FLT_MAX, rec) with world = the BVH root, for the lane's ray (o, d0);
 // d1 = unit_vector(d0).  FAST: bounded scene (crt_bvh.cpp: bvh_fast_ok).  force_general: test hook.
-template <bool FAST>
+// PRIMARY: o is the camera origin and `rec` the per-frame exact records; else any origin and `rec` = the
+// slot-ordered base records.  dir_used: direction of the winning triangle's test (for rec.p).
+template <bool FAST, bool PRIMARY = true>
 __device__ __forceinline__ void bvh_trace(const BvhView& b, const float* __restrict__ rec, V3 o, V3 d1, int force_mode,
-                                          float& best_t, int& best_slot) {
+                                          float& best_t, int& best_slot, V3& dir_used) {
     const V3 c1 = rot0_exact(b.rot, d1);
     const V3 c2 = chain_next<FAST>(b.rot, c1);
     const V3 c3 = chain_next<FAST>(b.rot, c2);
@@ -202,15 +240,21 @@ __device__ __forceinline__ void bvh_trace(const BvhView& b, const float* __restr
         const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
                                fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
         hot = lo >= 9.094947017729282e-13f;
+        if (!PRIMARY) {   // any origin: a coordinate difference below the fast division's range needs a tiny nonzero component
+            const float ax = fabsf(o.x), ay = fabsf(o.y), az = fabsf(o.z);
+            hot = hot && (ax == 0.0f || ax >= 1.3877787807814457e-17f) && (ay == 0.0f || ay >= 1.3877787807814457e-17f) &&
+                  (az == 0.0f || az >= 1.3877787807814457e-17f) && fmaxf(fmaxf(ax, ay), az) <= 1099511627776.0f;
+        }
     }
+    dir_used = c3;
     if (__builtin_amdgcn_ballot_w64(!hot) == 0ull) {
-        bvh_walk_fast(b, rec, o, c1, c2, c3, best_t, best_slot);
+        bvh_walk_fast<PRIMARY>(b, rec, o, c1, c2, c3, best_t, best_slot);
         return;
     }
     const V3 c5 = chain_next<FAST>(b.rot, c4);
     int mode = same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2);
     if (force_mode == 2) mode = 2;   // test hook: every lane iterates F from c4 (must give the same pixels)
-    bvh_walk_general<FAST>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot);
+    bvh_walk_general<FAST, PRIMARY>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot, dir_used);
 }
 
 // The render kernel with world = the BVH: lane = pixel, wavefront = 8x8 tile, block = 16x16.
@@ -228,7 +272,8 @@ render_bvh_kernel(RenderParams p, BvhView b, const float* __restrict__ rec, cons
     // lanes off the image replay a valid pixel (unstored): the traversal votes need whole wavefronts
     render_pixel<FAST, false, false>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, valid,
                                      [&](V3 d1, V3, float& closest, int& hit_idx) {
-        bvh_trace<FAST>(b, rec, o, d1, force_mode, closest, hit_idx);
+        V3 dir_used;
+        bvh_trace<FAST>(b, rec, o, d1, force_mode, closest, hit_idx, dir_used);
     });
 }
 

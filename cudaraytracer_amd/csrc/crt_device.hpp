@@ -138,6 +138,15 @@ constexpr int kStatsWords = 48;
 hipError_t launch_render_bvh(const RenderParams& p, const float4* d_nodes, int n_nodes, const float rot[9], const float* d_rec,
                              const float* d_shade_n, uint32_t* d_state, float* d_rgb, bool fast, int force_mode,
                              hipStream_t stream);
+// The generic render kernel (crt_shade_kernels.hpp): shader 0 LambertShade, 1 shade (recursive, depth
+// <= max_depth < kMaxShadeDepth), 2 shade_normal; world = list (d_nodes null) or BVH; per-triangle
+// materials (d_materials: array of {int kind; float albedo[3]; float param}).  d_base / d_shade_n /
+// d_material_of are in list order for the list world, in slot order for the BVH world.
+constexpr int kMaxShadeDepth = 31;
+hipError_t launch_render_generic(const RenderParams& p, const float* d_base, const float* d_shade_n, const int* d_material_of,
+                                 const void* d_materials, int n_tris, const float4* d_nodes, int n_nodes, const float rot[9],
+                                 uint32_t* d_state, float* d_rgb, bool bvh, bool fast, int shader, int max_depth, int force_mode,
+                                 hipStream_t stream);
 // One level of BVHNode::UpdateBVH: the nodes level_nodes[0..n_level) (all of one depth) recompute
 // their boxes from their triangles (leaves) or children (the deeper levels are already done).
 hipError_t launch_bvh_refit_level(float4* d_nodes, const int* d_level_nodes, int n_level, const float* d_base_slots,

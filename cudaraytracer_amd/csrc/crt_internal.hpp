@@ -52,6 +52,7 @@ Context* context_for(int device, hipStream_t stream);
 int ensure_records(Context& cx, int n_tris, int n_pad);
 int ensure_workspace(Context& ws, int nx, int rows);
 bool have_device();
+void rotation_zero_matrix(float m[9]);
 
 // ---------------------------------------------------------------- host vec3 helpers
 struct H3 {
@@ -92,6 +93,7 @@ struct crt_bvh {
     float* d_base_slots = nullptr;      // n x 12 base records in slot order
     float* d_shade_n_slots = nullptr;   // n x 3 shading normals in slot order (rotate(., 0) applied depth + 3 times)
     int* d_idx_slots = nullptr;         // n x 3 vertex indices in slot order (update_pose)
+    int* d_material_slots = nullptr;    // per-slot material index (null while the scene has a single material)
     int* d_level_nodes = nullptr;       // node indices grouped by depth
     std::vector<int> level_offset;      // level d = d_level_nodes[level_offset[d] .. level_offset[d + 1])
     std::vector<int> slot_tri;          // slot -> triangle index of the list
@@ -116,7 +118,16 @@ struct crt_scene {
     std::vector<float> h_base;    // host mirror of d_base (BVH build)
     std::vector<int> h_idx;       // host mirror of d_idx
     crt_bvh* bvh = nullptr;       // crt_scene_build_bvh
+    // materials (crt_scene_set_materials); default: one Lambertian(albedo), createScene.h:180
+    std::vector<crt_material> h_materials;
+    std::vector<int> h_material_of;   // per triangle (empty = all 0)
+    void* d_materials = nullptr;      // crt_material[n]
+    int* d_material_of = nullptr;     // list order (null = all 0)
+    bool single_lambertian = true;    // what the specialised LambertShade kernels assume
 };
+
+// (re)uploads the scene's per-slot material indices after a BVH build or a material change
+int upload_bvh_materials(crt_scene* s);
 
 struct crt_rng {
     long long first = 0, count = 0;

@@ -1857,5 +1857,6 @@ hipError_t launch_assemble_strips(const float* d_parts, long long part_stride, i
 }
 
 #include "crt_bvh_kernels.hpp"
+#include "crt_shade_kernels.hpp"
 
 }  // namespace crt

@@ -226,6 +226,37 @@ int crt_debug_bvh_export(const crt_scene *scene, float *boxes6, int *meta4, int 
 int crt_write_timing_csv(const char *path, int n_frames, const int *frame, const double *rendering,
                          const double *update, double build);
 
+/* ---- materials and shaders ---------------------------------------------------------
+ * replaces: the Material* of every Triangle (shapes/triangle.h:54) and the classes of
+ * material/material.h:57-161 over ConstantTexture (material/texture.h:12-22).  The scene pack
+ * (createScene.h:180) gives all triangles ONE Lambertian(albedo): that is every scene's default
+ * table {CRT_LAMBERTIAN, albedo}. */
+enum { CRT_LAMBERTIAN = 0, CRT_METAL = 1, CRT_DIELECTRIC = 2, CRT_DIFFUSE_LIGHT = 3 };
+typedef struct crt_material {
+    int kind;
+    float albedo[3]; /* Lambertian: albedo; Metal: albedo; DiffuseLight: emitted colour; Dielectric: unused */
+    float param;     /* Metal: fuzz (clamped to 1 like the ctor, material.h:79-81); Dielectric: ref_idx */
+} crt_material;
+/* table: n_materials entries; triangle_material: one table index per triangle of the list (NULL =
+ * all use entry 0).  Host pointers, copied. */
+int crt_scene_set_materials(crt_scene *scene, const crt_material *table, int n_materials,
+                            const int *triangle_material);
+
+/* The two things the reference selects by (un)commenting source lines, as arguments:
+ *   world   CRT_WORLD_LIST = the HitableList (renderListAnimation, core/render.h:179),
+ *           CRT_WORLD_BVH  = the BVHNode tree (renderBVHAnimation, core/render.h:222)
+ *   shader  the call at core/render.h:119-121: CRT_SHADER_LAMBERT = LambertShade (:70-87, the live
+ *           one), CRT_SHADER_SHADE = the recursive path tracer `shade` (:48-67; max_depth bounces,
+ *           0 <= max_depth <= 31), CRT_SHADER_NORMAL = shade_normal (:90-103).
+ * LambertShade on a single-Lambertian scene runs the specialised kernels (identical to
+ * crt_render_rows / crt_render_rows_bvh); everything else runs the generic kernel, which walks the
+ * whole list per ray in the list world, like the reference. */
+enum { CRT_WORLD_LIST = 0, CRT_WORLD_BVH = 1 };
+enum { CRT_SHADER_LAMBERT = 0, CRT_SHADER_SHADE = 1, CRT_SHADER_NORMAL = 2 };
+int crt_render_rows_ex(const crt_scene *scene, const crt_camera *camera, crt_rng *rng, int nx, int ny,
+                       int samples, int max_depth, int frame_index, int row_begin, int row_count,
+                       int world, int shader, float *d_rgb, void *stream);
+
 /* Kernel selection (diagnostics / A-B benchmarking), per calling thread. 0 = auto (default:
  * tiled when the scene and camera are finite and |coordinate| <= 2^38, else brute force),
  * 1 = brute-force list walk, 2 = tiled, 3 = tiled with a tiny survivor pool and heavy-tile

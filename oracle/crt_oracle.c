@@ -696,12 +696,98 @@ static o_vec3 random_in_unit_sphere(o_curand_state *state) {              /* mat
     return p;
 }
 
-static int lambertian_scatter(const o_world *w, const o_ray *r_in, const o_hitrec *rec,
-                              o_vec3 *attenuation, o_ray *scattered, o_curand_state *state) { /* material.h:61-71 */
-    o_vec3 target = add(add(rec->p, rec->normal), random_in_unit_sphere(state));
-    *scattered = make_ray(rec->p, sub(target, rec->p), r_in->_time);
-    *attenuation = w->albedo; /* ConstantTexture::value, texture.h:17-19 */
-    return 1;
+static o_vec3 reflect(o_vec3 v, o_vec3 n) {                               /* material.h:6-8 */
+    return sub(v, muls(2.0f * dot(v, n), n));
+}
+
+/* schlick, material.h:22-26.  pow((1.0f - cosine), 5.0f) is CUDA's powf in the reference, which
+ * no host libm reproduces bit for bit (PARITY UNPINNED here).  Rule adopted by the oracle and the
+ * kernels alike: the fifth power is formed in double (x*x, squared, times x) and rounded once to
+ * float — within one ulp of any faithful powf. */
+static float pow5f(float x) {
+    double p = (double)x, p2 = p * p, p4 = p2 * p2;
+    return (float)(p4 * p);
+}
+static float schlick(float cosine, float ref_idx) {
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * pow5f(1.0f - cosine);
+}
+
+static int refract(o_vec3 v, o_vec3 n, float ni_over_nt, o_vec3 *refracted) { /* material.h:29-39 */
+    o_vec3 uv = unit_vector(v);
+    float dt = dot(uv, n);
+    float discriminant = 1.0f - ni_over_nt * ni_over_nt * (1 - dt * dt);
+    if (discriminant > 0) {
+        *refracted = sub(muls(ni_over_nt, sub(uv, muls(dt, n))), muls(sqrtf(discriminant), n));
+        return 1;
+    } else
+        return 0;
+}
+
+static const o_material *material_of(const o_world *w, int tri) {
+    return &w->materials[w->material_of ? w->material_of[tri] : 0];
+}
+
+static o_vec3 material_emitted(const o_material *m) {                     /* material.h:49-53,157-159 */
+    if (m->kind == O_DIFFUSE_LIGHT) return m->albedo;
+    return v3(0, 0, 0);
+}
+
+/* Material::scatter of the four classes (material.h:57-161) */
+static int material_scatter(const o_material *m, const o_ray *r_in, const o_hitrec *rec,
+                            o_vec3 *attenuation, o_ray *scattered, o_curand_state *state) {
+    switch (m->kind) {
+    case O_LAMBERTIAN: {                                                  /* material.h:61-71 */
+        o_vec3 target = add(add(rec->p, rec->normal), random_in_unit_sphere(state));
+        *scattered = make_ray(rec->p, sub(target, rec->p), r_in->_time);
+        *attenuation = m->albedo;                                         /* ConstantTexture::value, texture.h:17-19 */
+        return 1;
+    }
+    case O_METAL: {                                                       /* material.h:83-92 */
+        float fuzz = m->param < 1 ? m->param : 1;                         /* ctor, material.h:79-81 */
+        o_vec3 reflected = reflect(unit_vector(r_in->_direction), rec->normal);
+        *scattered = make_ray(rec->p, add(reflected, muls(fuzz, random_in_unit_sphere(state))), 0.0f);
+        *attenuation = m->albedo;
+        return (dot(scattered->_direction, rec->normal) > 0.0f);
+    }
+    case O_DIELECTRIC: {                                                  /* material.h:103-141 */
+        float ref_idx = m->param;
+        o_vec3 outward_normal;
+        o_vec3 reflected = reflect(r_in->_direction, rec->normal);
+        float ni_over_nt;
+        *attenuation = v3(1.0, 1.0, 1.0);
+        o_vec3 refracted = v3(0, 0, 0);                                   /* uninitialised in the reference; only read after refract() wrote it ... */
+        float reflect_prob;
+        float cosine;
+        if (dot(r_in->_direction, rec->normal) > 0.0f) {
+            outward_normal = v3(-rec->normal.e[0], -rec->normal.e[1], -rec->normal.e[2]);
+            ni_over_nt = ref_idx;
+            cosine = dot(r_in->_direction, rec->normal) / length(r_in->_direction);
+            cosine = sqrtf(1 - ref_idx * ref_idx * (1 - cosine * cosine));
+        } else {
+            outward_normal = rec->normal;
+            ni_over_nt = 1.0f / ref_idx;
+            cosine = -dot(r_in->_direction, rec->normal) / length(r_in->_direction);
+        }
+        if (refract(r_in->_direction, outward_normal, ni_over_nt, &refracted)) {
+            reflect_prob = schlick(cosine, ref_idx);
+        } else {
+            reflect_prob = 1.0f;
+        }
+        /* ... except when reflect_prob is NaN (total internal reflection is 1.0f, so only a NaN
+         * cosine gets here with refract() == false): curand_uniform < NaN is false and the
+         * reference reads the uninitialised `refracted`; defined here as (0,0,0). */
+        if (o_curand_uniform(state) < reflect_prob) {
+            *scattered = make_ray(rec->p, reflected, 0.0f);
+        } else {
+            *scattered = make_ray(rec->p, refracted, 0.0f);
+        }
+        return 1;
+    }
+    default:                                                              /* DiffuseLight, material.h:147-156 */
+        return 0;
+    }
 }
 
 /* ------------------------------------------------------------------ core/render.h */
@@ -721,16 +807,34 @@ static int scene_hit(const o_scene_ref *sc, const o_ray *r, float t_min, float t
     return world_hit(sc->list, r, t_min, t_max, rec, NULL);
 }
 
-static o_vec3 LambertShade(const o_ray *r, const o_scene_ref *sc, int depth, o_curand_state *state, int frameIndex) { /* render.h:70-87 */
-    (void)depth; (void)frameIndex;
-    const o_world *world = sc->list;
+static o_vec3 shade(const o_ray *r, const o_scene_ref *sc, int depth, o_curand_state *state, int frameIndex) { /* render.h:48-67 */
     o_hitrec rec;
     memset(&rec, 0, sizeof rec);
     if (scene_hit(sc, r, 0.001, FLT_MAX, &rec)) {
+        const o_material *mat = material_of(sc->list, rec.tri);
         o_ray scattered;
         o_vec3 attenuation;
-        o_vec3 emitted = v3(0, 0, 0); /* Material::emitted, material.h:49-53 */
-        lambertian_scatter(world, r, &rec, &attenuation, &scattered, state);
+        o_vec3 emitted = material_emitted(mat);
+        if (depth > 0 && material_scatter(mat, r, &rec, &attenuation, &scattered, state)) {
+            return add(emitted, mulv(attenuation, shade(&scattered, sc, depth - 1, state, frameIndex)));
+        } else {
+            return add(emitted, v3(0.1, 0.1, 0.1));
+        }
+    } else {
+        return backgroundSky(r->_direction);
+    }
+}
+
+static o_vec3 LambertShade(const o_ray *r, const o_scene_ref *sc, int depth, o_curand_state *state, int frameIndex) { /* render.h:70-87 */
+    (void)depth; (void)frameIndex;
+    o_hitrec rec;
+    memset(&rec, 0, sizeof rec);
+    if (scene_hit(sc, r, 0.001, FLT_MAX, &rec)) {
+        const o_material *mat = material_of(sc->list, rec.tri);
+        o_ray scattered;
+        o_vec3 attenuation = v3(0, 0, 0); /* DiffuseLight::scatter leaves it unwritten (uninitialised in the reference): defined as 0 */
+        o_vec3 emitted = material_emitted(mat);
+        material_scatter(mat, r, &rec, &attenuation, &scattered, state);
         float t = dot(r->_direction, rec.normal);
         if (t < 0) t = 0;
         return add(muls(0.2, mulv(muls(t, attenuation), backgroundSky(r->_direction))), emitted);
@@ -739,7 +843,18 @@ static o_vec3 LambertShade(const o_ray *r, const o_scene_ref *sc, int depth, o_c
     }
 }
 
-static void render_window(float *colorBuffer, const o_scene_ref *world, const o_camera *camera,
+static o_vec3 shade_normal(const o_ray *r, const o_scene_ref *sc, int depth, o_curand_state *state, int frameIndex) { /* render.h:90-103 */
+    (void)depth; (void)state; (void)frameIndex;
+    o_hitrec rec;
+    memset(&rec, 0, sizeof rec);
+    if (scene_hit(sc, r, 0.001, FLT_MAX, &rec)) {
+        return rec.normal;
+    } else {
+        return backgroundSky(r->_direction);
+    }
+}
+
+static void render_window(float *colorBuffer, const o_scene_ref *world, int shader, const o_camera *camera,
                           o_curand_state *state, int nx, int ny, int samples, int max_depth,
                           int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
     /* render.h:105-129, one "thread" after another in pixel_index order */
@@ -753,7 +868,10 @@ static void render_window(float *colorBuffer, const o_scene_ref *world, const o_
                 float u = (float)(x + o_curand_uniform(&state[pixel_index])) / (float)nx;
                 float v = (float)(y + o_curand_uniform(&state[pixel_index])) / (float)ny;
                 o_ray r = get_ray(camera, u, v, state); /* base pointer: &state[0], render.h:118 */
-                col = add(col, LambertShade(&r, world, max_depth, &state[pixel_index], frameIndex));
+                /* render.h:119-121: the reference picks one of these three by (un)commenting */
+                if (shader == O_SHADER_SHADE) col = add(col, shade(&r, world, max_depth, &state[pixel_index], frameIndex));
+                else if (shader == O_SHADER_NORMAL) col = add(col, shade_normal(&r, world, 0, &state[pixel_index], frameIndex));
+                else col = add(col, LambertShade(&r, world, max_depth, &state[pixel_index], frameIndex));
             }
             col = div_assign_s(col, (float)ns);
             col.e[0] = sqrtf(col.e[0]);
@@ -770,14 +888,21 @@ void o_render_window(float *colorBuffer, const o_world *world, const o_camera *c
                      o_curand_state *state, int nx, int ny, int samples, int max_depth,
                      int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
     o_scene_ref sc = {world, NULL};                                       /* renderListAnimation, render.h:179 */
-    render_window(colorBuffer, &sc, camera, state, nx, ny, samples, max_depth, frameIndex, row_begin, row_end, col_begin, col_end);
+    render_window(colorBuffer, &sc, O_SHADER_LAMBERT, camera, state, nx, ny, samples, max_depth, frameIndex, row_begin, row_end, col_begin, col_end);
 }
 
 void o_render_window_bvh(float *colorBuffer, const o_bvh *bvh, const o_camera *camera,
                          o_curand_state *state, int nx, int ny, int samples, int max_depth,
                          int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
     o_scene_ref sc = {bvh->world, bvh};                                   /* renderBVHAnimation, render.h:222 */
-    render_window(colorBuffer, &sc, camera, state, nx, ny, samples, max_depth, frameIndex, row_begin, row_end, col_begin, col_end);
+    render_window(colorBuffer, &sc, O_SHADER_LAMBERT, camera, state, nx, ny, samples, max_depth, frameIndex, row_begin, row_end, col_begin, col_end);
+}
+
+void o_render_window_ex(float *colorBuffer, const o_world *world, const o_bvh *bvh, int shader,
+                        const o_camera *camera, o_curand_state *state, int nx, int ny, int samples,
+                        int max_depth, int frameIndex, int row_begin, int row_end, int col_begin, int col_end) {
+    o_scene_ref sc = {world, bvh};
+    render_window(colorBuffer, &sc, shader, camera, state, nx, ny, samples, max_depth, frameIndex, row_begin, row_end, col_begin, col_end);
 }
 
 void o_render(float *colorBuffer, const o_world *world, const o_camera *camera,
@@ -813,6 +938,11 @@ o_world *o_world_from_mesh(const float *points, int n_points, const float *idx3f
     w->list_size = n_tris;
     w->list = (o_triangle *)calloc(n_tris > 0 ? n_tris : 1, sizeof(o_triangle));
     w->albedo = v3(albedo[0], albedo[1], albedo[2]);
+    w->materials = (o_material *)calloc(1, sizeof(o_material));         /* new Lambertian(new ConstantTexture(...)), createScene.h:180 */
+    w->materials[0].kind = O_LAMBERTIAN;
+    w->materials[0].albedo = w->albedo;
+    w->n_materials = 1;
+    w->material_of = NULL;
     for (int i = 0; i < n_tris; i++) {
         int id[3];
         for (int k = 0; k < 3; k++) {
@@ -860,9 +990,31 @@ int o_world_update_pose(o_world *w, const float *new_points, int n_points, const
     return 0;
 }
 
+int o_world_set_materials(o_world *w, const o_material *table, int n_materials, const int *triangle_material) {
+    if (!w || !table || n_materials < 1) return -1;
+    for (int k = 0; k < n_materials; k++)
+        if (table[k].kind < O_LAMBERTIAN || table[k].kind > O_DIFFUSE_LIGHT) return -1;
+    if (triangle_material)
+        for (int i = 0; i < w->list_size; i++)
+            if (triangle_material[i] < 0 || triangle_material[i] >= n_materials) return -1;
+    free(w->materials);
+    free(w->material_of);
+    w->materials = (o_material *)malloc((size_t)n_materials * sizeof(o_material));
+    memcpy(w->materials, table, (size_t)n_materials * sizeof(o_material));
+    w->n_materials = n_materials;
+    w->material_of = NULL;
+    if (triangle_material) {
+        w->material_of = (int *)malloc((size_t)(w->list_size > 0 ? w->list_size : 1) * sizeof(int));
+        memcpy(w->material_of, triangle_material, (size_t)w->list_size * sizeof(int));
+    }
+    return 0;
+}
+
 void o_world_free(o_world *w) {
     if (!w) return;
     free(w->list);
+    free(w->materials);
+    free(w->material_of);
     free(w);
 }
 

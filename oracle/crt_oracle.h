@@ -53,13 +53,25 @@ typedef struct {
     int backCulling;
 } o_triangle;
 
-/* hitable/hitable_list.h:6-73 with a single shared Lambertian(ConstantTexture(albedo))
- * (createScene.h:180) */
+/* material/material.h:42-161 with ConstantTexture (material/texture.h:12-22) */
+enum { O_LAMBERTIAN = 0, O_METAL = 1, O_DIELECTRIC = 2, O_DIFFUSE_LIGHT = 3 };
+typedef struct {
+    int kind;
+    o_vec3 albedo;   /* Lambertian: albedo->value(); Metal: albedo; DiffuseLight: emit->value() */
+    float param;     /* Metal: fuzz as given (the ctor clamps it to 1, material.h:79-81); Dielectric: ref_idx */
+} o_material;
+
+/* hitable/hitable_list.h:6-73.  The scene pack gives every triangle one shared
+ * Lambertian(ConstantTexture(albedo)) (createScene.h:180): materials[0]; o_world_set_materials
+ * replaces the table and the per-triangle Material* (as indices). */
 typedef struct {
     o_transform transform;
     o_triangle *list;
     int list_size;
     o_vec3 albedo;
+    o_material *materials;
+    int n_materials;
+    int *material_of;   /* per triangle, NULL = all 0 */
 } o_world;
 
 /* core/aabb.h:14-55 */
@@ -102,6 +114,9 @@ void o_camera_init(o_camera *cam, const float lookfrom[3], const float lookat[3]
 o_world *o_world_from_mesh(const float *points, int n_points, const float *idx3f,
                            int n_tris, const float *normals, int index_base,
                            const float albedo[3]);
+/* Triangle::material per triangle (triangle.h:54): table + one index per triangle (NULL = all 0).
+ * -1: bad index or kind. */
+int o_world_set_materials(o_world *w, const o_material *table, int n_materials, const int *triangle_material);
 /* createScene.h:99-110 update_pose: new vertex positions, normals kept.  -1: index out of range. */
 int o_world_update_pose(o_world *w, const float *new_points, int n_points, const float *idx3f, int index_base);
 void o_world_free(o_world *w);
@@ -140,6 +155,17 @@ void o_render_window_bvh(float *colorBuffer, const o_bvh *bvh, const o_camera *c
                          o_curand_state *state, int nx, int ny, int samples, int max_depth,
                          int frameIndex, int row_begin, int row_end, int col_begin,
                          int col_end);
+
+/* The render kernel with an explicit choice of the two things the reference selects by
+ * (un)commenting source lines: the world (bvh == NULL: the list, render.h:179; else the BVH,
+ * render.h:222) and the shader called at core/render.h:119-121 — O_SHADER_LAMBERT = LambertShade
+ * (:70-87, the live one), O_SHADER_SHADE = the recursive path tracer `shade` (:48-67),
+ * O_SHADER_NORMAL = shade_normal (:90-103). */
+enum { O_SHADER_LAMBERT = 0, O_SHADER_SHADE = 1, O_SHADER_NORMAL = 2 };
+void o_render_window_ex(float *colorBuffer, const o_world *world, const o_bvh *bvh, int shader,
+                        const o_camera *camera, o_curand_state *state, int nx, int ny, int samples,
+                        int max_depth, int frameIndex, int row_begin, int row_end, int col_begin,
+                        int col_end);
 
 /* Diagnostics for tests: closest hit of ONE ray through the world list
  * (core/render.h:75 -> hitable.h:29-38 -> hitable_list.h:76-91). Returns hit flag. */

@@ -33,6 +33,14 @@ class Camera(C.Structure):
                [("lens_radius", C.c_float)]
 
 
+class Material(C.Structure):
+    """o_material (crt_oracle.h)."""
+    _fields_ = [("kind", C.c_int), ("albedo", C.c_float * 3), ("param", C.c_float)]
+
+
+LAMBERTIAN, METAL, DIELECTRIC, DIFFUSE_LIGHT = 0, 1, 2, 3
+SHADER_LAMBERT, SHADER_SHADE, SHADER_NORMAL = 0, 1, 2
+
 STATE_DTYPE = np.dtype([("d", np.uint32), ("v", np.uint32, (5,))])
 
 # o_bvh_node (crt_oracle.h): 2 transforms (9 floats each), box (6 floats), 8 ints
@@ -78,6 +86,9 @@ def lib():
         L.o_bvh_order.restype = C.c_void_p
         L.o_bvh_hit.argtypes = [C.c_void_p, fp, fp, fp, C.POINTER(C.c_int), fp]
         L.o_bvh_hit.restype = C.c_int
+        L.o_world_set_materials.argtypes = [C.c_void_p, C.POINTER(Material), C.c_int, C.POINTER(C.c_int)]
+        L.o_world_set_materials.restype = C.c_int
+        L.o_render_window_ex.argtypes = [fp, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Camera), C.c_void_p] + [C.c_int] * 9
         L.o_render_window_bvh.argtypes = [fp, C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_int] * 9
         _lib = L
     return _lib
@@ -134,6 +145,20 @@ class World:
             raise ValueError("o_world_from_mesh: vertex index out of range")
         self.n_tris = len(self.idx3f)
         self.index_base = index_base
+
+    def set_materials(self, table, triangle_material=None):
+        """table: [(kind, (r, g, b), param), ...]; triangle_material: one index per triangle or None."""
+        arr = (Material * len(table))()
+        for k, (kind, albedo, param) in enumerate(table):
+            arr[k].kind = int(kind)
+            arr[k].albedo = (C.c_float * 3)(*[float(x) for x in albedo])
+            arr[k].param = float(param)
+        of = None
+        if triangle_material is not None:
+            tm = np.ascontiguousarray(triangle_material, dtype=np.int32)
+            of = tm.ctypes.data_as(C.POINTER(C.c_int))
+        if lib().o_world_set_materials(self.handle, arr, len(table), of) != 0:
+            raise ValueError("o_world_set_materials: bad table or index")
 
     def update_pose(self, new_points):
         """update_pose (createScene.h:99-110): new vertex positions, stored normals kept."""
@@ -214,6 +239,17 @@ def render_bvh(bvh, cam, nx, ny, samples, states, window=None, max_depth=8, fram
     buf = np.zeros((ny, nx, 3), dtype=np.float32)
     lib().o_render_window_bvh(_fp(buf), bvh.handle, C.byref(cam), states.ctypes.data,
                               nx, ny, samples, max_depth, frame, r0, r1, c0, c1)
+    return buf, states
+
+
+def render_ex(world, bvh, shader, cam, nx, ny, samples, states, window=None, max_depth=8, frame=0):
+    """The render kernel with an explicit world (bvh None = the list) and shader (render.h:119-121)."""
+    if window is None:
+        window = (0, ny, 0, nx)
+    r0, r1, c0, c1 = window
+    buf = np.zeros((ny, nx, 3), dtype=np.float32)
+    lib().o_render_window_ex(_fp(buf), world.handle, bvh.handle if bvh is not None else None, int(shader), C.byref(cam),
+                             states.ctypes.data, nx, ny, samples, max_depth, frame, r0, r1, c0, c1)
     return buf, states
 
 

@@ -1,0 +1,183 @@
+"""The reference's other two shaders and its material classes: recursive `shade`
+(core/render.h:48-67), shade_normal (:90-103), Metal / Dielectric / DiffuseLight
+(material/material.h:77-161), on both worlds.  CPU: the oracle's restatement against closed forms;
+GPU (marked): the generic kernel against the oracle through crt_render_rows_ex.
+
+PARITY UNPINNED additionally at pow(1 - cosine, 5.0f) (schlick, material.h:25): CUDA's powf is not
+reproducible off-device; oracle and kernels form the fifth power in double and round once."""
+import numpy as np
+import pytest
+
+from cudaraytracer_amd import _lib, api, scenes
+
+MATS = [(api.LAMBERTIAN, (0.73, 0.73, 0.73), 0.0), (api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0),
+        (api.LAMBERTIAN, (0.12, 0.45, 0.15), 0.0), (api.DIFFUSE_LIGHT, (15.0, 15.0, 15.0), 0.0),
+        (api.METAL, (0.8, 0.85, 0.88), 0.1), (api.DIELECTRIC, (1.0, 1.0, 1.0), 1.5), (api.METAL, (0.7, 0.6, 0.5), 3.0)]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def same(a, b):
+    """Bit equality; NaNs match NaNs (the payload of sqrt(negative) differs between x86 and gfx950)."""
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    return bool(((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def material_scene(kind):
+    """(scene dict, per-triangle material indices): meshes whose boxes are not flat, so that both
+    worlds see them."""
+    if kind == "cornell":
+        sc = scenes.cornell32()
+        of = np.zeros(32, np.int32)
+        of[6:8], of[8:10], of[10:12], of[12:22], of[22:32] = 1, 2, 3, 4, 5
+    elif kind == "spheres":
+        a = scenes.displaced_sphere(10, 14, radius=120.0, centre=(-140.0, 150.0, 0.0))
+        b = scenes.displaced_sphere(10, 14, radius=120.0, centre=(140.0, 150.0, 0.0))
+        g = scenes.displaced_sphere(6, 8, radius=900.0, centre=(0.0, -880.0, 0.0), amp=0.0)
+        pts = np.concatenate([a["points"], b["points"], g["points"]]).astype(np.float32)
+        idx = np.concatenate([a["idx"], b["idx"] + len(a["points"]), g["idx"] + len(a["points"]) + len(b["points"])]).astype(np.float32)
+        sc = dict(points=pts, idx=idx, normals=None, index_base=0, camera=dict(scenes.REFERENCE_CAMERA))
+        of = np.concatenate([np.full(len(a["idx"]), 4), np.full(len(b["idx"]), 5), np.full(len(g["idx"]), 2)]).astype(np.int32)
+        of[::7] = 3                                   # some lights
+        of[3::11] = 6                                 # fuzz > 1 (clamped by the ctor)
+    else:
+        sc = scenes.random_soup(60, 9)
+        of = (np.arange(60) % len(MATS)).astype(np.int32)
+    return sc, of
+
+
+def oracle_world(oracle, sc, of, nx, ny):
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    w.set_materials(MATS, of)
+    c = sc["camera"]
+    cam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
+    return w, cam
+
+
+# ------------------------------------------------------------------ oracle (CPU)
+def test_oracle_shade_closed_forms(oracle):
+    """One big triangle in front of the camera covering the image centre."""
+    pts = np.array([[-50, -50, -5.5], [50, -50, -5], [0, 50, -4.5]], dtype=np.float32)
+    idx = np.array([[0, 1, 2]], dtype=np.float32)
+    nrm = np.array([[0, 0, -1]], dtype=np.float32)
+    nx = ny = 8
+    cam = oracle.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 40.0, np.float32(1), 0.0, 10.0)
+
+    def centre(kind, albedo, shader, depth):
+        w = oracle.World(pts, idx, nrm, 0)
+        w.set_materials([(kind, albedo, 1.5)])
+        img, _ = oracle.render_ex(w, None, shader, cam, nx, ny, 2, oracle.fresh_states(nx, ny), max_depth=depth)
+        return img[4, 4]
+
+    light = centre(oracle.DIFFUSE_LIGHT, (0.25, 0.5, 0.04), oracle.SHADER_SHADE, 8)
+    # DiffuseLight never scatters: emitted + vec3(0.1), then sqrt, clip
+    want = np.sqrt(np.array([0.25, 0.5, 0.04], dtype=np.float32) + np.float32(0.1)).astype(np.float32)
+    assert np.allclose(light, want, atol=1e-6)
+    # depth 0: scatter is not even called -> 0 + 0.1 for any material that does not emit
+    for kind in (oracle.LAMBERTIAN, oracle.METAL, oracle.DIELECTRIC):
+        assert np.allclose(centre(kind, (0.9, 0.9, 0.9), oracle.SHADER_SHADE, 0), np.sqrt(np.float32(0.1)), atol=1e-6)
+    # shade_normal returns rec.normal: (0, 0, -1) -> sqrt(0), sqrt(0), sqrt(-1) = NaN, which clip() passes through
+    n = centre(oracle.LAMBERTIAN, (0.5, 0.5, 0.5), oracle.SHADER_NORMAL, 8)
+    assert n[0] == 0 and n[1] == 0 and np.isnan(n[2])
+    # a dielectric slab seen head-on reflects a little and transmits the sky
+    glass = centre(oracle.DIELECTRIC, (1, 1, 1), oracle.SHADER_SHADE, 8)
+    assert np.isfinite(glass).all() and glass.min() > 0.3
+
+
+def test_oracle_lambert_shade_is_unchanged_by_the_default_material_table(oracle, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "sphere1000_96x54x4.npz"))
+    sc = scenes.displaced_sphere(20, 25)
+    nx, ny, spp = int(g["nx"]), int(g["ny"]), int(g["spp"])
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    c = sc["camera"]
+    cam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny), 0.0, 10.0)
+    img, _ = oracle.render_ex(w, None, oracle.SHADER_LAMBERT, cam, nx, ny, spp, oracle.fresh_states(nx, ny))
+    assert np.array_equal(bits(img), bits(g["rgb"]))
+    w.set_materials([(oracle.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0)])
+    img, _ = oracle.render_ex(w, None, oracle.SHADER_LAMBERT, cam, nx, ny, spp, oracle.fresh_states(nx, ny))
+    assert np.array_equal(bits(img), bits(g["rgb"]))
+
+
+def test_material_table_validation(crt_built):
+    if crt_built.crt_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    assert crt_built.crt_scene_set_materials(None, None, 0, None) == _lib.CRT_ERR_INVALID
+    assert crt_built.crt_render_rows_ex(None, None, None, 8, 8, 1, 8, 0, 0, 8, 7, 0, None, None) == _lib.CRT_ERR_INVALID
+
+
+# ------------------------------------------------------------------ product vs oracle (GPU)
+def hip_render(gpu, scene, cam, st, nx, ny, spp, world, shader, depth, variant=0):
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    prev = _lib.lib().crt_set_kernel_variant(variant)
+    try:
+        api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=world, shader=shader, max_depth=depth,
+                           stream=gpu.cuda.current_stream())
+        gpu.cuda.synchronize()
+    finally:
+        _lib.lib().crt_set_kernel_variant(prev)
+    return d.cpu().numpy().reshape(ny, nx, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cornell", "spheres", "soup"])
+@pytest.mark.parametrize("world", ["list", "bvh"])
+def test_gpu_shaders_and_materials_match_oracle(gpu, oracle, kind, world):
+    """All three shaders, all four material classes, max_depth 0 / 1 / 8, both worlds; RNG states
+    after the frame included (the number of draws depends on every bounce)."""
+    sc, of = material_scene(kind)
+    nx, ny, spp = (48, 36, 3) if kind != "soup" else (32, 24, 2)
+    w, ocam = oracle_world(oracle, sc, of, nx, ny)
+    scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    c = sc["camera"]
+    cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+    if world == "bvh":                                 # built before the materials are set: the slot order must follow
+        api.create_BVHfromList(scene, None, seed=0)
+    scene.set_materials(MATS, of)
+    for shader, depth in [(api.SHADER_SHADE, 8), (api.SHADER_SHADE, 1), (api.SHADER_SHADE, 0), (api.SHADER_LAMBERT, 8),
+                          (api.SHADER_NORMAL, 8)]:
+        states = oracle.fresh_states(nx, ny)
+        bvh = oracle.Bvh(w, states) if world == "bvh" else None
+        ref, states = oracle.render_ex(w, bvh, shader, ocam, nx, ny, spp, states, max_depth=depth)
+        after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+        for variant in ((0, 5, 6) if world == "bvh" and shader == api.SHADER_SHADE and depth == 8 else (0,)):
+            st = api.SetCurandState(nx, ny, 0)
+            if world == "bvh":
+                api.create_BVHfromList(scene, st)      # the reference's order: SetCurandState, build, render
+            got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH if world == "bvh" else api.WORLD_LIST, shader, depth, variant)
+            assert same(got, ref), (shader, depth, variant, float(np.nanmax(np.abs(got - ref))))
+            assert np.array_equal(st.export()[1:], after[1:]), (shader, depth, variant)
+
+
+@pytest.mark.gpu
+def test_gpu_lambert_entry_points_follow_the_material_table(gpu, oracle):
+    """crt_render_rows / crt_render_rows_bvh on a scene whose table is not one Lambertian run the
+    generic kernel (same pixels as the oracle's LambertShade with those materials); setting the
+    table back to one Lambertian restores the specialised kernels and their pixels."""
+    sc, of = material_scene("spheres")
+    nx, ny, spp = 64, 40, 2
+    w, ocam = oracle_world(oracle, sc, of, nx, ny)
+    scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    c = sc["camera"]
+    cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+    scene.set_materials(MATS, of)
+    ref, _ = oracle.render_ex(w, None, oracle.SHADER_LAMBERT, ocam, nx, ny, spp, oracle.fresh_states(nx, ny))
+    st = api.SetCurandState(nx, ny, 0)
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=gpu.cuda.current_stream())
+    gpu.cuda.synchronize()
+    assert same(d.cpu().numpy().reshape(ny, nx, 3), ref)
+    one = [(api.LAMBERTIAN, (0.2, 0.4, 0.6), 0.0)]
+    scene.set_materials(one)
+    w.set_materials(one)
+    ref, _ = oracle.render_ex(w, None, oracle.SHADER_LAMBERT, ocam, nx, ny, spp, oracle.fresh_states(nx, ny))
+    st = api.SetCurandState(nx, ny, 0)
+    api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=gpu.cuda.current_stream())
+    gpu.cuda.synchronize()
+    assert same(d.cpu().numpy().reshape(ny, nx, 3), ref)
+    with pytest.raises(_lib.CrtError):
+        api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, shader=api.SHADER_SHADE, max_depth=40)
+    with pytest.raises(_lib.CrtError):
+        scene.set_materials([(9, (0, 0, 0), 0.0)])
