@@ -766,9 +766,6 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         HIP_TRY(hipEventCreate(&cx.ev_mid));
     }
     HIP_TRY(hipEventRecord(cx.ev_start, stream));   // the per-frame prepasses count as binning time
-    if (!generic)
-    HIP_TRY(crt::launch_tri_prepass(world == 1 ? scene->bvh->d_base_slots : scene->d_base, scene->n_tris, camera->origin,
-                                    cx.d_rec, stream));
 
     // public variant numbering (crt_set_kernel_variant): 0 auto, 1 brute force, 2 tiled,
     // 3 tiled with tiny list capacities (exercises the overflow fallbacks)
@@ -822,6 +819,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         return CRT_OK;
     }
     if (world == 1) {
+        HIP_TRY(crt::launch_tri_prepass(scene->bvh->d_base_slots, scene->n_tris, camera->origin, cx.d_rec, stream));
         // fast arithmetic of the traversal: bounded scene and origin, no nonzero coordinate below 2^-56
         // (crt_bvh_kernels.hpp: box_hit_fast); otherwise the literal IEEE loop
         bool fast = scene->tiled_safe && scene->bvh->coords_not_tiny;
@@ -838,14 +836,17 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         cx.ev_valid = true;
         return CRT_OK;
     }
-    if (kernel_variant != 0) {
+    if (kernel_variant != 0) {   // one launch: exact + classification records, scratch zeroed
         int rc = ensure_workspace(cx, nx, row_count);
         if (rc != CRT_OK) return rc;
-        HIP_TRY(crt::launch_cls_prepass(cx.d_rec, scene->n_tris, scene->n_pad, p, cx.d_cls, stream));
+        HIP_TRY(crt::launch_frame_prepass(scene->d_base, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
+    } else {
+        HIP_TRY(crt::launch_tri_prepass(scene->d_base, scene->n_tris, camera->origin, cx.d_rec, stream));
     }
     HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
                                d_rgb, kernel_variant, kernel_variant ? &cx.w : nullptr, cx.n_cus,
-                               scene->tiled_safe && cam_ok, g_d_stats, kernel_variant ? cx.ev_mid : nullptr, &cx.cache, stream));
+                               scene->tiled_safe && cam_ok, g_d_stats, kernel_variant ? cx.ev_mid : nullptr, &cx.cache,
+                               kernel_variant != 0, stream));
     cx.ev_has_mid = kernel_variant != 0;
     HIP_TRY(hipEventRecord(cx.ev_stop, stream));
     cx.ev_valid = true;

@@ -118,7 +118,12 @@ struct LaunchCache {
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
-                         hipEvent_t ev_mid, LaunchCache* cache, hipStream_t stream);
+                         hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream);
+// The per-frame prepass of the tiled variant in ONE launch: exact records (tri_prepass) + classification
+// records (cls_prepass) + zeroing of this frame's binning scratch (w.tile_count, w.counters);
+// launch_render is then called with prezeroed = true.
+hipError_t launch_frame_prepass(const float* d_base, int n_tris, int n_pad, const RenderParams& p, float* d_rec, float4* d_cls,
+                                const TiledWork& w, hipStream_t stream);
 // Multi-GPU reassembly on rank 0 (dist: strips of `strip_rows` rows dealt round-robin to `world`
 // ranks): parts[r * part_stride ...] holds rank r's strips one after the other; every strip is
 // copied to its rows of the full nx x ny float3 frame.

@@ -132,12 +132,7 @@ hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long c
 // ------------------------------------------------------------------ triangle prepass
 // Per triangle, once per camera origin: the ray-independent part of
 // Triangle::collision_detection (shapes/triangle.h:69-70,81,87,92) in its own order.
-__global__ void __launch_bounds__(256)
-tri_prepass_kernel(const float* __restrict__ base, int n, float ox, float oy, float oz,
-                   float* __restrict__ rec) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* b = base + (size_t)i * kBaseFloats;
+__device__ __forceinline__ void derive_record(const float* __restrict__ b, float ox, float oy, float oz, float4 o[4]) {
     float v0x = b[0], v0y = b[1], v0z = b[2];
     float v1x = b[3], v1y = b[4], v1z = b[5];
     float v2x = b[6], v2y = b[7], v2z = b[8];
@@ -148,11 +143,21 @@ tri_prepass_kernel(const float* __restrict__ base, int n, float ox, float oy, fl
     float qy = (-(sx * e1z - sz * e1x));
     float qz = (sx * e1y - sy * e1x);
     float tq = e2x * qx + e2y * qy + e2z * qz;                     // dot(edge2, q)
-    float4* o = reinterpret_cast<float4*>(rec + (size_t)i * kRecFloats);
     o[0] = make_float4(b[9], b[10], b[11], e2x);
     o[1] = make_float4(e2y, e2z, e1x, e1y);
     o[2] = make_float4(e1z, sx, sy, sz);
     o[3] = make_float4(qx, qy, qz, tq);
+}
+
+__global__ void __launch_bounds__(256)
+tri_prepass_kernel(const float* __restrict__ base, int n, float ox, float oy, float oz,
+                   float* __restrict__ rec) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 r4[4];
+    derive_record(base + (size_t)i * kBaseFloats, ox, oy, oz, r4);
+    float4* o = reinterpret_cast<float4*>(rec + (size_t)i * kRecFloats);
+    o[0] = r4[0]; o[1] = r4[1]; o[2] = r4[2]; o[3] = r4[3];
 }
 
 // update_pose (createScene.h:99-110; a single device thread in the reference): lane = triangle,
@@ -930,11 +935,14 @@ bin_alloc_kernel(TiledWork w, int heavy_min, unsigned shade_blocks, unsigned lon
 
 // binning of one launch: count, allocate, fill (all on `stream`)
 static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int n_pad, const TiledWork& w,
-                                 int heavy_min, unsigned shade_blocks, unsigned long long* d_stats, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(w.tile_count, 0, (size_t)w.tiles_total * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+                                 int heavy_min, unsigned shade_blocks, unsigned long long* d_stats, bool prezeroed, hipStream_t stream) {
+    hipError_t e = hipSuccess;
+    if (!prezeroed) {   // launch_frame_prepass zeroes the scratch of its frame itself
+        e = hipMemsetAsync(w.counters, 0, kCtrWords * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(w.tile_count, 0, (size_t)w.tiles_total * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
     const int region_nx = (w.tiles_x + kRegionTilesX - 1) / kRegionTilesX, region_ny = (w.tiles_y + kRegionTilesY - 1) / kRegionTilesY;
     const int n_waves = (p.n_tris + kBinThreads - 1) / kBinThreads;
     int waves_min = kBinWavesMin, few = kFewTriangles;
@@ -1436,15 +1444,38 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 
 // Classification prepass: per triangle, the exact (fp64) affine coefficients of the four
 // forms over d0(u,v) = (llc - o) + u*H + v*V, rounded to fp32, and the magnitudes M.
+// FUSED (the per-frame prepass of the tiled variant, one launch): the exact record is derived from the
+// base record right here (tri_prepass's arithmetic) and written out, and the launch also zeroes
+// the binning scratch of this frame (tile counts and the counter block) — three launches less.
 constexpr int kClsThreads = 64;
+template <bool FUSED>
 __global__ void __launch_bounds__(kClsThreads)
-cls_prepass_kernel(const float* __restrict__ rec, int n, int n_pad, RenderParams p,
-                   float4* __restrict__ cls) {
+cls_prepass_kernel(const float* __restrict__ rec_in, const float* __restrict__ base, float* __restrict__ rec_out, int n, int n_pad,
+                   RenderParams p, float4* __restrict__ cls, uint32_t* __restrict__ zero_a, int n_zero_a,
+                   uint32_t* __restrict__ zero_b, int n_zero_b) {
     __shared__ double poly[2][2][10][kClsThreads];   // clip polygons: [ping-pong][x|y][vertex][lane], 20 KB
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (FUSED) {
+        const int stride = (int)(gridDim.x * blockDim.x);
+        for (int k = i; k < n_zero_a; k += stride) zero_a[k] = 0u;
+        for (int k = i; k < n_zero_b; k += stride) zero_b[k] = 0u;
+    }
     if (i >= n) return;
     const CameraPOD& cam = p.cam;
-    const float* r = rec + (size_t)i * kRecFloats;
+    float r[kRecFloats];
+    if (FUSED) {
+        float4 r4[4];
+        derive_record(base + (size_t)i * kBaseFloats, cam.origin[0], cam.origin[1], cam.origin[2], r4);
+        float4* o = reinterpret_cast<float4*>(rec_out + (size_t)i * kRecFloats);
+        o[0] = r4[0]; o[1] = r4[1]; o[2] = r4[2]; o[3] = r4[3];
+        r[0] = r4[0].x; r[1] = r4[0].y; r[2] = r4[0].z; r[3] = r4[0].w; r[4] = r4[1].x; r[5] = r4[1].y; r[6] = r4[1].z; r[7] = r4[1].w;
+        r[8] = r4[2].x; r[9] = r4[2].y; r[10] = r4[2].z; r[11] = r4[2].w; r[12] = r4[3].x; r[13] = r4[3].y; r[14] = r4[3].z; r[15] = r4[3].w;
+    } else {
+        const float4* ri = reinterpret_cast<const float4*>(rec_in + (size_t)i * kRecFloats);
+        const float4 a = ri[0], b4 = ri[1], c4 = ri[2], d4 = ri[3];
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b4.x; r[5] = b4.y; r[6] = b4.z; r[7] = b4.w;
+        r[8] = c4.x; r[9] = c4.y; r[10] = c4.z; r[11] = c4.w; r[12] = d4.x; r[13] = d4.y; r[14] = d4.z; r[15] = d4.w;
+    }
     const double nx = r[0], ny = r[1], nz = r[2];
     const double e2x = r[3], e2y = r[4], e2z = r[5];
     const double e1x = r[6], e1y = r[7], e1z = r[8];
@@ -1559,14 +1590,25 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const R
                               float4* d_cls, hipStream_t stream) {
     if (n_tris <= 0) return hipSuccess;
     dim3 block(kClsThreads), grid((unsigned)((n_tris + kClsThreads - 1) / kClsThreads));
-    hipLaunchKernelGGL(cls_prepass_kernel, grid, block, 0, stream, d_rec, n_tris, n_pad, p, d_cls);
+    hipLaunchKernelGGL(cls_prepass_kernel<false>, grid, block, 0, stream, d_rec, (const float*)nullptr, (float*)nullptr, n_tris, n_pad, p,
+                       d_cls, (uint32_t*)nullptr, 0, (uint32_t*)nullptr, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_prepass(const float* d_base, int n_tris, int n_pad, const RenderParams& p, float* d_rec, float4* d_cls,
+                                const TiledWork& w, hipStream_t stream) {
+    // enough blocks for the triangles and for zeroing the scratch in at most 16 words per thread
+    const long long zero_words = (long long)w.tiles_total + kCtrWords;
+    const unsigned blocks = (unsigned)std::max<long long>((n_tris + kClsThreads - 1) / kClsThreads, (zero_words + kClsThreads * 16 - 1) / (kClsThreads * 16));
+    hipLaunchKernelGGL(cls_prepass_kernel<true>, dim3(std::max(blocks, 1u)), dim3(kClsThreads), 0, stream, (const float*)nullptr, d_base, d_rec,
+                       n_tris, n_pad, p, d_cls, w.tile_count, w.tiles_total, w.counters, kCtrWords);
     return hipGetLastError();
 }
 
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
-                         hipEvent_t ev_mid, LaunchCache* cache, hipStream_t stream) {
+                         hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     if (variant == 0 || d_cls == nullptr || work == nullptr) {
         dim3 block(256);
@@ -1623,7 +1665,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* ev = getenv("CRT_SHADE_GRID")) n_blocks = std::max(1, atoi(ev));
 #endif
     n_blocks = std::max(1, std::min(n_blocks, w.tiles_total));
-    e = launch_binning(p, d_cls, n_pad, w, heavy, (unsigned)n_blocks, d_stats, stream);
+    e = launch_binning(p, d_cls, n_pad, w, heavy, (unsigned)n_blocks, d_stats, prezeroed, stream);
     if (e != hipSuccess) return e;
     if (ev_mid) {
         e = hipEventRecord(ev_mid, stream);   // splits the timing: [start, mid) = binning, [mid, stop) = shading
@@ -1734,7 +1776,7 @@ hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4*
                         const uint32_t* d_state, const TiledWork* work, unsigned long long* d_counters,
                         hipStream_t stream) {
     TiledWork w = *work;
-    hipError_t e = launch_binning(p, d_cls, n_pad, w, kHeavyMin, 0u, nullptr, stream);
+    hipError_t e = launch_binning(p, d_cls, n_pad, w, kHeavyMin, 0u, nullptr, false, stream);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)((w.tiles_x + 1) / 2), (unsigned)((w.tiles_y + 1) / 2));
     hipLaunchKernelGGL(audit_tiles_kernel, grid, dim3(256), 0, stream, p, d_rec, d_cls, n_pad, d_state, w, d_counters);
