@@ -583,6 +583,98 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
     state[5 * stride + si] = rs.v4;
 }
 
+// A wave-uniform float in a VGPR.  On gfx950 a VALU instruction with an SGPR source issues at half the
+// rate of a VGPR-only one (profiles/r1_ubench_valu2.txt: 4.1 vs 2.3 cycles per wave64 instruction);
+// the empty asm hides the value's origin, so hipcc keeps using the register copy inside the loop.
+__device__ __forceinline__ float in_vgpr(float x) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+
+// The `render` kernel for a pixel of a tile WITHOUT survivors: every sample is background
+// (render.h:85), which needs unit_vector(d0).y only.  Same arithmetic as render_pixel<true, true>;
+// the camera and the reciprocals live in VGPRs for the loop (VGPR-only operands), and the range
+// guard of the fast quotient is decided once per tile when the tile's d0.y cannot come near zero:
+// d0.y is affine in (u, v), so its range over the tile follows from the four corners, and
+// |d0| <= 2^40 holds for every bounded camera.
+__device__ __forceinline__ void render_sky_pixel(const RenderParams& p, int x, int ly, uint32_t* __restrict__ state,
+                                                 float* __restrict__ rgb) {
+    const int y = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
+    const long long pixel_index = (long long)y * p.nx + x;
+    const long long si = (long long)ly * p.nx + x, stride = p.rng_count;
+    Xorwow rs;
+    rs.d = state[0 * stride + si]; rs.v0 = state[1 * stride + si]; rs.v1 = state[2 * stride + si];
+    rs.v2 = state[3 * stride + si]; rs.v3 = state[4 * stride + si]; rs.v4 = state[5 * stride + si];
+    const CameraPOD& c = p.cam;
+    const float llx = in_vgpr(c.llc[0]), lly = in_vgpr(c.llc[1]), llz = in_vgpr(c.llc[2]);
+    const float hx = in_vgpr(c.horizontal[0]), hy = in_vgpr(c.horizontal[1]), hz = in_vgpr(c.horizontal[2]);
+    const float vx = in_vgpr(c.vertical[0]), vy = in_vgpr(c.vertical[1]), vz = in_vgpr(c.vertical[2]);
+    const float ox = in_vgpr(c.origin[0]), oy = in_vgpr(c.origin[1]), oz = in_vgpr(c.origin[2]);
+    const float fnx = in_vgpr((float)p.nx), fny = in_vgpr((float)p.ny), rnx = in_vgpr(p.rnx), rny = in_vgpr(p.rny);
+    const float fx = (float)x, fy = (float)y;
+    // can some ray of this wavefront's tile have |d0.y| < 2^-30 or a huge length?  (u, v) of the tile lie in
+    // [x0/nx, (x0+8)/nx] x [y0/ny, (y0+8)/ny] up to rounding; a margin of one pixel each way covers that.
+    bool guard_needed;
+    {
+        const float u0 = ((float)(x & ~7) - 1.0f) * p.rnx, u1 = ((float)(x & ~7) + 9.0f) * p.rnx;
+        const float v0 = ((float)(y & ~7) - 1.0f) * p.rny, v1 = ((float)(y & ~7) + 9.0f) * p.rny;
+        float lo = 3.0e38f, hi = -3.0e38f, mag = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float uu = (k & 1) ? u1 : u0, vv = (k & 2) ? v1 : v0;
+            const float dy = ((c.llc[1] + uu * c.horizontal[1]) + vv * c.vertical[1]) - c.origin[1];
+            lo = fminf(lo, dy);
+            hi = fmaxf(hi, dy);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) mag += fabsf(c.llc[k]) + fabsf(c.horizontal[k]) + fabsf(c.vertical[k]) + fabsf(c.origin[k]);
+        // safe: over the tile d0.y keeps one sign with |d0.y| >= 2^-20 mag at the corners; the float evaluation here and
+        // per sample is within 2^-22 mag of the affine model each, so every sample has |d0.y| >= 2^-21 mag >= 2^-39,
+        // and |d0| <= sqrt(3) mag < 2^40: the conditions unit_vector_fast_y votes on hold for all of them
+        const float thr = mag * 9.5367431640625e-7f;   // 2^-20 mag
+        const bool safe = mag < 274877906944.0f && thr >= 3.637978807091713e-12f && ((lo > 0.0f && lo >= thr) || (hi < 0.0f && -hi >= thr));
+        guard_needed = __builtin_amdgcn_ballot_w64(!safe) != 0ull;
+    }
+    float colx = 0.0f, coly = 0.0f, colz = 0.0f;
+    for (int smp = 0; smp < p.samples; ++smp) {
+        const float u = div_by_rcp(fx + xw_uniform(rs), fnx, rnx);     // render.h:116
+        const float v = div_by_rcp(fy + xw_uniform(rs), fny, rny);     // render.h:117
+        if (pixel_index == 0) {                                        // lens sample from state[0] (render.h:118): DESIGN.md §1
+            float px, py;
+            do {
+                px = 2.0f * xw_uniform(rs) - 1.0f;
+                py = 2.0f * xw_uniform(rs) - 1.0f;
+            } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);
+        }
+        const float dx = ((llx + u * hx) + v * vx) - ox;               // camera.h:43
+        const float dy = ((lly + u * hy) + v * vy) - oy;
+        const float dz = ((llz + u * hz) + v * vz) - oz;
+        float uy;
+        if (guard_needed) {
+            uy = unit_vector_fast_y(V3{dx, dy, dz});
+        } else {   // unit_vector_fast_y without its per-sample range vote
+            const float s2 = dx * dx + dy * dy + dz * dz;
+            const float len = sqrt_normal(s2);
+            uy = div_by_rcp(dy, len, reciprocal<true>(len));
+        }
+        const float t = 0.5f * (uy + 1.0f);                            // backgroundSky, render.h:41-46
+        colx += 1.0f + t * (0.5f - 1.0f);
+        coly += 1.0f + t * (0.7f - 1.0f);
+        colz += 1.0f + t * (1.0f - 1.0f);
+    }
+    const float k = (float)(1.0 / (double)(float)p.samples);           // vec3.h:182-189
+    colx *= k; coly *= k; colz *= k;
+    colx = sqrtf(colx); coly = sqrtf(coly); colz = sqrtf(colz);         // render.h:124-126
+    colx = (colx > 1.0f) ? 1.0f : ((colx < 0.0f) ? 0.0f : colx);        // clip, vec3.h:119-131
+    coly = (coly > 1.0f) ? 1.0f : ((coly < 0.0f) ? 0.0f : coly);
+    colz = (colz > 1.0f) ? 1.0f : ((colz < 0.0f) ? 0.0f : colz);
+    const size_t o = ((size_t)ly * p.nx + x) * 3;
+    rgb[o + 0] = colx; rgb[o + 1] = coly; rgb[o + 2] = colz;
+    state[0 * stride + si] = rs.d; state[1 * stride + si] = rs.v0; state[2 * stride + si] = rs.v1;
+    state[3 * stride + si] = rs.v2; state[4 * stride + si] = rs.v3; state[5 * stride + si] = rs.v4;
+}
+
 // ---------------------------------------------------------------- variant 0: brute force
 // One lane = one pixel; one wavefront = an 8x8 pixel tile; one 256-thread block = 16x16.
 // Every ray walks the whole list.
@@ -1325,9 +1417,15 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         light_len[c] = w.counters[kCtrQueueLen + kHeavyClasses + c];
         n_light += light_len[c];
     }
+    // Items are dealt to the chunks in groups of kLightGroup consecutive queue positions: within a class the
+    // queue follows the tile index, so a group is mostly a run of horizontally adjacent tiles, and the wave that
+    // takes them one after the other writes their framebuffer rows back to back — 4 x 96 B of a row are three
+    // full 128-B lines in the same L2 instead of four separately evicted partial ones.
+    constexpr unsigned kLightGroup = 4;
+    const unsigned n_groups = (n_light + kLightGroup - 1) / kLightGroup;
     int chunk = (int)((blockIdx.x * WAVES + wave) % kLightChunks);
     while (true) {
-        const unsigned c_len = (n_light + (unsigned)(kLightChunks - 1 - chunk)) / kLightChunks;   // items g = pos * 64 + chunk < n_light
+        const unsigned c_len = ((n_groups + (unsigned)(kLightChunks - 1 - chunk)) / kLightChunks) * kLightGroup;   // positions of this chunk
         unsigned pos = 0xffffffffu;
         if (c_len != 0u) {
             if (lane == 0) pos = atomicAdd(&w.counters[kCtrLightCursor + chunk * kCtrLine], 1u);
@@ -1336,7 +1434,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         if (pos >= c_len) {   // chunk exhausted (or empty): look at all cursors at once
             unsigned left = 0;
             if (lane < kLightChunks) {
-                const unsigned len_l = (n_light + (unsigned)(kLightChunks - 1 - lane)) / kLightChunks;
+                const unsigned len_l = ((n_groups + (unsigned)(kLightChunks - 1 - lane)) / kLightChunks) * kLightGroup;
                 const unsigned cur = __hip_atomic_load(&w.counters[kCtrLightCursor + lane * kCtrLine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 left = (cur < len_l) ? 1u : 0u;
             }
@@ -1347,7 +1445,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             chunk = (r + (int)__builtin_ctzll(rot)) & (kLightChunks - 1);
             continue;
         }
-        unsigned item = pos * kLightChunks + (unsigned)chunk;
+        unsigned item = ((pos / kLightGroup) * kLightChunks + (unsigned)chunk) * kLightGroup + pos % kLightGroup;
+        if (item >= n_light) continue;                                 // the tail of the last group
         int lc = 0;
 #pragma unroll
         for (int c = 0; c < kLightClasses - 1; ++c)
@@ -1393,8 +1492,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         }
         const bool pair_mode = n_pairs != 0xffffffffu;
         if (cnt == 0) {   // background only (most tiles of a typical frame)
-            if (x < p.nx && ly < p.row_count)
-                render_pixel<true, true>(p, x, ly, shade_n, state, rgb, true, [](V3, V3, float&, int&) {});
+            if (x < p.nx && ly < p.row_count) render_sky_pixel(p, x, ly, state, rgb);
         } else if (pair_mode) {   // all 64 lanes stay active (ds_bpermute reads lanes); off-image lanes replay a valid pixel, unstored
             render_pixel<true>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, x < p.nx && ly < p.row_count,
                          [&](V3, V3 d2, float& closest, int& hit_idx) {

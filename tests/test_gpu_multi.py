@@ -140,3 +140,29 @@ def test_single_process_driver_on_one_device(gpu, oracle):
     assert np.array_equal(bits(f1).reshape(-1, 3)[1:], bits(r1).reshape(-1, 3)[1:])   # pixel 0 of frame 1: DESIGN.md §1
     with pytest.raises(_lib.CrtError):
         api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 99)
+
+
+def test_cpp_driver_program(gpu, oracle, tmp_path):
+    """cudaraytracer_amd/crt_driver (csrc/crt_driver.cpp): the C++ host program in place of the
+    reference's main() — OBJ in, PNG per frame + output.csv out, C ABI only.  Its frame equals the
+    oracle's (BVH world, LambertShade, the reference's live configuration)."""
+    import os
+    import subprocess
+    from test_abi import decode_png
+    exe = os.path.join(os.path.dirname(_lib.library_path()), "crt_driver")
+    assert os.path.exists(exe), "run make -C cudaraytracer_amd/csrc"
+    sc = scenes.displaced_sphere(16, 20, index_base=1)
+    obj = scenes.write_obj(str(tmp_path / "m.obj"), sc)
+    nx, ny, spp = 96, 64, 2
+    out, csv = str(tmp_path / "frames"), str(tmp_path / "output.csv")
+    subprocess.check_call([exe, "--obj", obj, "--scale", "1", "--width", str(nx), "--height", str(ny), "--spp", str(spp),
+                           "--frames", "2", "--world", "bvh", "--out", out, "--csv", csv], cwd=str(tmp_path))
+    pts, idx = oracle.parse_obj(obj)
+    w = oracle.World(pts, idx, None, 1)
+    cam = oracle.make_camera((0, 100, 1000), (0, 150, 0), (0, 1, 0), 40.0, np.float32(nx) / np.float32(ny), 0.0, 10.0)
+    states = oracle.fresh_states(nx, ny)
+    bvh = oracle.Bvh(w, states)
+    ref, states = oracle.render_bvh(bvh, cam, nx, ny, spp, states)
+    assert np.array_equal(decode_png(os.path.join(out, "picture_0.png")), oracle.to_rgba8(ref))
+    rows = open(csv).read().splitlines()
+    assert rows[0] == "frame,rendering,update,build" and rows[1].startswith(",,,") and rows[2].startswith("0,") and rows[3].startswith("1,")
