@@ -59,59 +59,85 @@ __device__ __forceinline__ float xw_uniform(Xorwow& s) {
 // The 2^67-step subsequence skip is a product of precomputed GF(2) matrices
 // J_k = T^(2^(67+k)), one per set bit of pixel_index.  Matrix rows are wave-uniform
 // scalar loads; each lane masks them with its own state bits.
+// One matrix-vector product: r = v * M (row-vector convention), M wave-uniform.
+__device__ __forceinline__ void xw_matvec(const uint32_t* __restrict__ M, const uint32_t v[kXwWords], uint32_t r[kXwWords]) {
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+#pragma unroll
+    for (int w = 0; w < kXwWords; ++w) {
+        uint32_t word = v[w];
+        for (int b = 0; b < 32; ++b) {
+            uint32_t mask = 0u - ((word >> b) & 1u);
+            const uint32_t* row = M + (size_t)(w * 32 + b) * kXwWords;   // uniform address
+            r0 ^= row[0] & mask;
+            r1 ^= row[1] & mask;
+            r2 ^= row[2] & mask;
+            r3 ^= row[3] & mask;
+            r4 ^= row[4] & mask;
+        }
+    }
+    r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4;
+}
+
+// Element i of the state array belongs to pixel x = i % nx of local row i / nx.  A thread derives the
+// state of its FIRST element from the seed (one product per set bit of the pixel index: ~10 for a
+// 1080p frame), then walks kRngRun - 1 further elements 64 apart with ONE product each: elements 64
+// apart inside a row are 64 pixels apart, i.e. one application of J_6 = T^(2^73) (the table's entry
+// for bit 6).  A wavefront thus covers kRngRun * 64 consecutive elements with coalesced stores, at
+// roughly (10 + kRngRun - 1) / kRngRun products per pixel instead of 10.  A lane whose step leaves the
+// row (or crosses into another strip) starts over from the seed.
+constexpr int kRngRun = 16;
 __global__ void __launch_bounds__(256)
 rng_init_kernel(uint32_t* __restrict__ state, long long first_pixel, int nx, int strip_rows, int strip_step,
                 long long count, uint32_t seed_lo, uint32_t seed_hi, const uint32_t* __restrict__ jump,
                 int nbits) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = i < count;
-    const long long il = live ? i : 0;
-    const int ly = (int)(il / nx), x = (int)(il % nx);
-    // subsequence = GLOBAL pixel index y*nx + x (deviceManage.h:126-127)
-    unsigned long long pi = (unsigned long long)first_pixel +
-                            (unsigned long long)global_row(0, strip_rows, strip_step, ly) * (unsigned long long)nx +
-                            (unsigned long long)x;
+    const long long wave_id = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const long long i0 = wave_id * (64 * kRngRun) + lane;
 
     // _curand_init_scratch seed scrambling
-    uint32_t s0 = seed_lo ^ 0xaad26b49u;
-    uint32_t s1 = seed_hi ^ 0xf7dcefddu;
-    uint32_t t0 = 1099087573u * s0;
-    uint32_t t1 = 2591861531u * s1;
-    uint32_t d = 6615241u + t1 + t0;
-    uint32_t v[kXwWords];
-    v[0] = 123456789u + t0;
-    v[1] = 362436069u ^ t0;
-    v[2] = 521288629u + t1;
-    v[3] = 88675123u ^ t1;
-    v[4] = 5783321u + t0;
-
-    for (int k = 0; k < nbits; ++k) {
-        bool take = live && ((pi >> k) & 1ull);
-        if (__builtin_amdgcn_ballot_w64(take) == 0ull) continue;   // wave-uniform skip
-        const uint32_t* __restrict__ M = jump + (size_t)k * kXwBits * kXwWords;
-        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
-#pragma unroll
-        for (int w = 0; w < kXwWords; ++w) {
-            uint32_t word = v[w];
-            for (int b = 0; b < 32; ++b) {
-                uint32_t mask = 0u - ((word >> b) & 1u);
-                const uint32_t* row = M + (size_t)(w * 32 + b) * kXwWords;   // uniform address
-                r0 ^= row[0] & mask;
-                r1 ^= row[1] & mask;
-                r2 ^= row[2] & mask;
-                r3 ^= row[3] & mask;
-                r4 ^= row[4] & mask;
+    const uint32_t s0 = seed_lo ^ 0xaad26b49u;
+    const uint32_t s1 = seed_hi ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0;
+    const uint32_t t1 = 2591861531u * s1;
+    const uint32_t d = 6615241u + t1 + t0;
+    uint32_t v[kXwWords] = {0u, 0u, 0u, 0u, 0u};
+    unsigned long long prev_pi = 0ull;
+    bool have_prev = false;
+    for (int j = 0; j < kRngRun; ++j) {
+        const long long i = i0 + 64ll * j;
+        const bool live = i < count;
+        if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
+        const long long il = live ? i : 0;
+        const int ly = (int)(il / nx), x = (int)(il % nx);
+        // subsequence = GLOBAL pixel index y*nx + x (deviceManage.h:126-127)
+        const unsigned long long pi = (unsigned long long)first_pixel +
+                                      (unsigned long long)global_row(0, strip_rows, strip_step, ly) * (unsigned long long)nx +
+                                      (unsigned long long)x;
+        const bool step = have_prev && live && pi == prev_pi + 64ull;   // the same stream family, 64 subsequences on
+        uint32_t stepped[kXwWords] = {0u, 0u, 0u, 0u, 0u};
+        if (__builtin_amdgcn_ballot_w64(step) != 0ull) xw_matvec(jump + (size_t)6 * kXwBits * kXwWords, v, stepped);
+        if (__builtin_amdgcn_ballot_w64(live && !step) != 0ull) {       // some lane starts from the seed (first element, row change)
+            uint32_t f[kXwWords] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
+            for (int k = 0; k < nbits; ++k) {
+                const bool take = live && !step && ((pi >> k) & 1ull);
+                if (__builtin_amdgcn_ballot_w64(take) == 0ull) continue;   // wave-uniform skip
+                uint32_t r[kXwWords];
+                xw_matvec(jump + (size_t)k * kXwBits * kXwWords, f, r);
+                if (take) { f[0] = r[0]; f[1] = r[1]; f[2] = r[2]; f[3] = r[3]; f[4] = r[4]; }
             }
+            if (!step) { stepped[0] = f[0]; stepped[1] = f[1]; stepped[2] = f[2]; stepped[3] = f[3]; stepped[4] = f[4]; }
         }
-        if (take) { v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3; v[4] = r4; }
-    }
-    if (live) {   // SoA: coalesced
-        state[0 * count + i] = d;
-        state[1 * count + i] = v[0];
-        state[2 * count + i] = v[1];
-        state[3 * count + i] = v[2];
-        state[4 * count + i] = v[3];
-        state[5 * count + i] = v[4];
+        v[0] = stepped[0]; v[1] = stepped[1]; v[2] = stepped[2]; v[3] = stepped[3]; v[4] = stepped[4];
+        prev_pi = pi;
+        have_prev = live;
+        if (live) {   // SoA: coalesced
+            state[0 * count + i] = d;
+            state[1 * count + i] = v[0];
+            state[2 * count + i] = v[1];
+            state[3 * count + i] = v[2];
+            state[4 * count + i] = v[3];
+            state[5 * count + i] = v[4];
+        }
     }
 }
 
@@ -123,7 +149,8 @@ hipError_t launch_rng_init(uint32_t* d_state, long long first_pixel, long long c
                               (unsigned long long)(global_row(0, strip_rows, strip_step, last_ly) + 1) * (unsigned long long)nx;
     int nbits = 0;
     while (nbits < kXwJumps && (last >> nbits) != 0ull) ++nbits;
-    dim3 block(256), grid((unsigned)((count + 255) / 256));
+    const long long waves = (count + 64 * kRngRun - 1) / (64 * kRngRun);
+    dim3 block(256), grid((unsigned)((waves + 3) / 4));
     hipLaunchKernelGGL(rng_init_kernel, grid, block, 0, stream, d_state, first_pixel, nx, strip_rows, strip_step,
                        count, (uint32_t)seed, (uint32_t)(seed >> 32), d_jump, nbits);
     return hipGetLastError();
@@ -463,6 +490,15 @@ __device__ __forceinline__ void exact_test_vec(const RecV& rc, int i_raw, V3 d, 
     }
 }
 
+// A wave-uniform float in a VGPR.  On gfx950 a VALU instruction with an SGPR source issues at half the
+// rate of a VGPR-only one (profiles/r1_ubench_valu2.txt: 4.1 vs 2.3 cycles per wave64 instruction);
+// the empty asm hides the value's origin, so hipcc keeps using the register copy inside the loop.
+__device__ __forceinline__ float in_vgpr(float x) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+
 // The body of the `render` kernel for one pixel (core/render.h:105-129).  `traverse(d2,
 // closest, hit_idx)` must return the result of HitableList::collision_detection
 // (hitable/hitable_list.h:76-91): minimum t over all triangles that pass
@@ -491,13 +527,26 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 
     const CameraPOD& c = p.cam;
     float colx = 0.0f, coly = 0.0f, colz = 0.0f;
-    const float fnx = (float)p.nx, fny = (float)p.ny;
+#ifndef CRT_VGPR_CAM
+#define CRT_VGPR_CAM 0
+#endif
+    const bool kVgprCam = FASTDIV && CRT_VGPR_CAM;   // experiment: ray set-up constants in VGPRs (see in_vgpr)
+    const float fnx = kVgprCam ? in_vgpr((float)p.nx) : (float)p.nx, fny = kVgprCam ? in_vgpr((float)p.ny) : (float)p.ny;
+    const float rnx = kVgprCam ? in_vgpr(p.rnx) : p.rnx, rny = kVgprCam ? in_vgpr(p.rny) : p.rny;
+    CameraPOD cv = c;
+    if (kVgprCam) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cv.llc[k] = in_vgpr(c.llc[k]); cv.horizontal[k] = in_vgpr(c.horizontal[k]);
+            cv.vertical[k] = in_vgpr(c.vertical[k]); cv.origin[k] = in_vgpr(c.origin[k]);
+        }
+    }
 
     for (int smp = 0; smp < p.samples; ++smp) {
         float u, v;
         if (FASTDIV) {   // same bits as the IEEE divides (see div_by_rcp; numerators >= 2^-33, divisors 1..2^24)
-            u = div_by_rcp((float)x + xw_uniform(rs), fnx, p.rnx);     // render.h:116
-            v = div_by_rcp((float)y + xw_uniform(rs), fny, p.rny);     // render.h:117
+            u = div_by_rcp((float)x + xw_uniform(rs), fnx, rnx);       // render.h:116
+            v = div_by_rcp((float)y + xw_uniform(rs), fny, rny);       // render.h:117
         } else {
             u = ((float)x + xw_uniform(rs)) / fnx;                     // render.h:116
             v = ((float)y + xw_uniform(rs)) / fny;                     // render.h:117
@@ -513,7 +562,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
             } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);          // dot(p,p) with p.z = 2*0-0
         }
         // direction = lower_left_corner + s*horizontal + t*vertical - origin - offset, offset = 0
-        V3 d0 = camera_direction(c, u, v);
+        V3 d0 = camera_direction(cv, u, v);
 
         if (SKYONLY) {   // a tile without survivors: every sample is background, which needs unit_vector(d0).y only
             const V3 sky = sky_from_unit(V3{0.0f, unit_vector_fast_y(d0), 0.0f});
@@ -581,15 +630,6 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
     state[3 * stride + si] = rs.v2;
     state[4 * stride + si] = rs.v3;
     state[5 * stride + si] = rs.v4;
-}
-
-// A wave-uniform float in a VGPR.  On gfx950 a VALU instruction with an SGPR source issues at half the
-// rate of a VGPR-only one (profiles/r1_ubench_valu2.txt: 4.1 vs 2.3 cycles per wave64 instruction);
-// the empty asm hides the value's origin, so hipcc keeps using the register copy inside the loop.
-__device__ __forceinline__ float in_vgpr(float x) {
-    float v;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
-    return v;
 }
 
 // The `render` kernel for a pixel of a tile WITHOUT survivors: every sample is background
