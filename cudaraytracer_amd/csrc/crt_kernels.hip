@@ -528,7 +528,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
     const CameraPOD& c = p.cam;
     float colx = 0.0f, coly = 0.0f, colz = 0.0f;
 #ifndef CRT_VGPR_CAM
-#define CRT_VGPR_CAM 0
+#define CRT_VGPR_CAM 1   // measured on the bench frame: shade 0.816 -> 0.769 ms (profiles/r2_tiled/sweep_occ.txt)
 #endif
     const bool kVgprCam = FASTDIV && CRT_VGPR_CAM;   // experiment: ray set-up constants in VGPRs (see in_vgpr)
     const float fnx = kVgprCam ? in_vgpr((float)p.nx) : (float)p.nx, fny = kVgprCam ? in_vgpr((float)p.ny) : (float)p.ny;
