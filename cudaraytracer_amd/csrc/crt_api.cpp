@@ -819,7 +819,6 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         return CRT_OK;
     }
     if (world == 1) {
-        HIP_TRY(crt::launch_tri_prepass(scene->bvh->d_base_slots, scene->n_tris, camera->origin, cx.d_rec, stream));
         // fast arithmetic of the traversal: bounded scene and origin, no nonzero coordinate below 2^-56
         // (crt_bvh_kernels.hpp: box_hit_fast); otherwise the literal IEEE loop
         bool fast = scene->tiled_safe && scene->bvh->coords_not_tiny;
@@ -828,6 +827,22 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
             fast = fast && std::isfinite(o) && fabsf(o) <= 274877906944.0f && (o == 0.0f || fabsf(o) >= 1.3877787807814457e-17f);
             fast = fast && std::isfinite(camera->lower_left_corner[k]) && std::isfinite(camera->horizontal[k]) && std::isfinite(camera->vertical[k]);
         }
+        // Primary rays ride the tiled kernels (binning over the slot-ordered triangles, the tree only for every
+        // pixel's winner: shade_tiles_kernel<.., BVH>) whenever the list world's tiled variant is eligible and
+        // the fast arithmetic holds; variant 1 (and the test hooks 5, 6) select the per-ray tree walk.
+        if (fast && tiled_ok && (g_variant == 0 || g_variant == 2)) {
+            int rc = ensure_workspace(cx, nx, row_count);
+            if (rc != CRT_OK) return rc;
+            HIP_TRY(crt::launch_frame_prepass(scene->bvh->d_base_slots, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
+            HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, 1, &cx.w,
+                                       cx.n_cus, true, g_d_stats, cx.ev_mid, &cx.cache_bvh, true, stream,
+                                       static_cast<const crt::BvhTiles*>(scene->bvh->d_tiles_view)));
+            cx.ev_has_mid = true;
+            HIP_TRY(hipEventRecord(cx.ev_stop, stream));
+            cx.ev_valid = true;
+            return CRT_OK;
+        }
+        HIP_TRY(crt::launch_tri_prepass(scene->bvh->d_base_slots, scene->n_tris, camera->origin, cx.d_rec, stream));
         const int force_mode = g_variant == 5 ? 1 : (g_variant == 6 ? 2 : 0);
         HIP_TRY(crt::launch_render_bvh(p, scene->bvh->d_nodes, scene->bvh->n_nodes, scene->bvh->rot, cx.d_rec,
                                        scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, fast, force_mode, stream));

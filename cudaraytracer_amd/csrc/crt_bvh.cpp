@@ -179,6 +179,10 @@ crt_bvh::~crt_bvh() {
     if (d_idx_slots) (void)hipFree(d_idx_slots);
     if (d_level_nodes) (void)hipFree(d_level_nodes);
     if (d_material_slots) (void)hipFree(d_material_slots);
+    if (d_partner) (void)hipFree(d_partner);
+    if (d_slot_leaf) (void)hipFree(d_slot_leaf);
+    if (d_anc) (void)hipFree(d_anc);
+    if (d_tiles_view) (void)hipFree(d_tiles_view);
 }
 
 extern "C" {
@@ -245,6 +249,30 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
         levels[nd.depth].push_back(i);
         for (int k = 0; k < nd.count; ++k) slot_depth[nd.first + k] = nd.depth;
     }
+    // tiled primary rays: tie order, leaf of every slot, path of every leaf
+    std::vector<int> partner(n), slot_leaf(n), path;
+    t->anc_stride = (b.max_depth + 1 + 3) / 4 * 4;
+    std::vector<int> anc;
+    {
+        int n_leaves = 0;
+        for (int i = 0; i < t->n_nodes; ++i) n_leaves += b.nodes[i].count != 0;
+        anc.assign((size_t)n_leaves * t->anc_stride, -1);
+        int ord = 0;
+        path.clear();
+        for (int i = 0; i < t->n_nodes; ++i) {   // preorder: the node at depth d replaces the path's entry d
+            const HostNode& nd = b.nodes[i];
+            path.resize(nd.depth);
+            path.push_back(i);
+            if (nd.count == 0) continue;
+            for (int k = 0; k <= nd.depth; ++k) anc[(size_t)ord * t->anc_stride + k] = path[k];
+            for (int k = 0; k < nd.count; ++k) {
+                const int slot = nd.first + k;
+                slot_leaf[slot] = ord | (nd.depth << 24);
+                partner[slot] = nd.count == 2 ? nd.first + (1 - k) : slot;
+            }
+            ++ord;
+        }
+    }
     std::vector<int> level_nodes;
     t->level_offset.assign(1, 0);
     for (const std::vector<int>& lv : levels) {
@@ -277,6 +305,20 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
     if (e == hipSuccess) e = hipMemcpy(t->d_shade_n_slots, shade_slots.data(), shade_slots.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->d_idx_slots, idx_slots.data(), idx_slots.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->d_level_nodes, level_nodes.data(), level_nodes.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&t->d_partner, partner.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&t->d_slot_leaf, slot_leaf.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&t->d_anc, anc.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&t->d_tiles_view, sizeof(crt::BvhTiles));
+    if (e == hipSuccess) e = hipMemcpy(t->d_partner, partner.data(), partner.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->d_slot_leaf, slot_leaf.data(), slot_leaf.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->d_anc, anc.data(), anc.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        crt::BvhTiles view;
+        view.nodes = t->d_nodes; view.n_nodes = t->n_nodes; view.partner = t->d_partner; view.slot_leaf = t->d_slot_leaf;
+        view.anc = t->d_anc; view.anc_stride = t->anc_stride;
+        memcpy(view.rot, rotm, sizeof rotm);
+        e = hipMemcpy(t->d_tiles_view, &view, sizeof view, hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && have_stream0) {   // the stream moved on by one draw per node
         const uint32_t w[6] = {b.rng.d, b.rng.v[0], b.rng.v[1], b.rng.v[2], b.rng.v[3], b.rng.v[4]};
         for (int k = 0; k < 6 && e == hipSuccess; ++k)

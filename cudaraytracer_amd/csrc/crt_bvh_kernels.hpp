@@ -257,6 +257,28 @@ __device__ __forceinline__ void bvh_trace(const BvhView& b, const float* __restr
     bvh_walk_general<FAST, PRIMARY>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot, dir_used);
 }
 
+// The boxes of a slot's leaf and of all its ancestors, each with the direction of its depth
+// (hot chain: c1 for the root, c2 for its children, c3 below), as BVHNode::collision_detection
+// meets them on the way down (bvh.h:164).  Used by the tiled kernel's BVH mode for the winner of
+// a pixel: lanes call it independently.
+__device__ __forceinline__ bool chain_ok(const BvhTiles& bt, int slot, V3 o, V3 c1, V3 c2, V3 c3) {
+    const int info = bt.slot_leaf[slot];
+    const int ord = info & 0xffffff, depth = (info >> 24) & 31;
+    const int* __restrict__ path = bt.anc + (size_t)ord * bt.anc_stride;
+    const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
+    for (int k = depth; k >= 0; --k) {   // leaf first: small boxes fail first
+        const int node = path[k];
+        const float4 n0 = bt.nodes[2 * (size_t)node], n1 = bt.nodes[2 * (size_t)node + 1];
+        V3 d = c3, y = y3;
+        if (k < 2) {
+            d = k == 0 ? c1 : c2;
+            y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
+        }
+        if (!box_hit_fast(n0, n1, o, d, y)) return false;
+    }
+    return true;
+}
+
 // The render kernel with world = the BVH: lane = pixel, wavefront = 8x8 tile, block = 16x16.
 template <bool FAST>
 __global__ void __launch_bounds__(256)

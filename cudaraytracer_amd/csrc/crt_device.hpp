@@ -115,10 +115,12 @@ struct LaunchCache {
     const void* fn = nullptr;
     int resident = 0;
 };
+struct BvhTiles;
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
-                         hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream);
+                         hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream,
+                         const BvhTiles* d_bvh_tiles = nullptr);
 // The per-frame prepass of the tiled variant in ONE launch: exact records (tri_prepass) + classification
 // records (cls_prepass) + zeroing of this frame's binning scratch (w.tile_count, w.counters);
 // launch_render is then called with prezeroed = true.
@@ -152,6 +154,21 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
                                  const void* d_materials, int n_tris, const float4* d_nodes, int n_nodes, const float rot[9],
                                  uint32_t* d_state, float* d_rgb, bool bvh, bool fast, int shader, int max_depth, int force_mode,
                                  hipStream_t stream);
+// What the tiled kernels need of the tree to serve the BVH world's PRIMARY rays:
+// a triangle is hit through the tree iff it passes Triangle::collision_detection AND the boxes of its
+// leaf and of all the leaf's ancestors pass AABB::hit — the tile lists (a superset of the first
+// condition) give the candidates, the chain of boxes is checked for the winner of every pixel.
+struct BvhTiles {
+    const float4* nodes;     // flat tree (crt_bvh_kernels.hpp)
+    int n_nodes;
+    const int* partner;      // per slot s: r(s) = s with the two slots of a 2-triangle leaf swapped.  The tree keeps, among equal t,
+                             // the LAST leaf and inside a leaf the FIRST triangle (bvh.h:172-179, hitable_list.h:84): the larger r wins.
+    const int* slot_leaf;    // per slot: leaf ordinal (bits 0..23) | leaf depth << 24
+    const int* anc;          // per leaf ordinal: node indices of the path root..leaf, anc_stride ints each
+    int anc_stride;
+    float rot[9];            // rotate(., 0) matrix
+};
+
 // One level of BVHNode::UpdateBVH: the nodes level_nodes[0..n_level) (all of one depth) recompute
 // their boxes from their triangles (leaves) or children (the deeper levels are already done).
 hipError_t launch_bvh_refit_level(float4* d_nodes, const int* d_level_nodes, int n_level, const float* d_base_slots,

@@ -45,7 +45,7 @@ struct Context {
     size_t rec_cap = 0, cls_cap = 0; // in triangles
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
     bool ev_has_mid = false, ev_valid = false;
-    crt::LaunchCache cache;
+    crt::LaunchCache cache, cache_bvh;
 };
 
 Context* context_for(int device, hipStream_t stream);
@@ -94,6 +94,12 @@ struct crt_bvh {
     float* d_shade_n_slots = nullptr;   // n x 3 shading normals in slot order (rotate(., 0) applied depth + 3 times)
     int* d_idx_slots = nullptr;         // n x 3 vertex indices in slot order (update_pose)
     int* d_material_slots = nullptr;    // per-slot material index (null while the scene has a single material)
+    // primary rays through the tiled kernels (crt_kernels.hip: shade_tiles_kernel<.., BVH = true>)
+    int* d_partner = nullptr;           // per slot: the slot with the two slots of a 2-triangle leaf swapped (tie order, see BvhTiles)
+    int* d_slot_leaf = nullptr;         // per slot: leaf ordinal | leaf depth << 24
+    int* d_anc = nullptr;               // per leaf ordinal: node indices root..leaf, anc_stride ints (-1 padded)
+    int anc_stride = 0;
+    void* d_tiles_view = nullptr;       // crt::BvhTiles on the device
     int* d_level_nodes = nullptr;       // node indices grouped by depth
     std::vector<int> level_offset;      // level d = d_level_nodes[level_offset[d] .. level_offset[d + 1])
     std::vector<int> slot_tri;          // slot -> triangle index of the list

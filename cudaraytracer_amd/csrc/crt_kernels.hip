@@ -734,6 +734,8 @@ render_list_kernel(RenderParams p, const float* __restrict__ rec,
     });
 }
 
+#include "crt_bvh_kernels.hpp"   // BVH world: traversal kernel + the device functions the tiled kernel's BVH mode shares
+
 // ---------------------------------------------------------------- variant 1: tiled
 // Same pixels, far fewer tests.  A triangle can only be hit by a ray of a screen rectangle
 // if the reference's own float predicates can pass for some direction of that rectangle.
@@ -1317,11 +1319,20 @@ __device__ __forceinline__ void trace_pairs(StageArea& area, const int* ent, con
 // the entries against ITS pixel (stage_candidates) and the surviving (pixel, entry) pairs are
 // walked evenly spread over the lanes (build_pairs / trace_pairs; trace_candidates when they
 // do not fit);  !VREC (variant 4, A/B): wave-uniform walks with scalar-operand records.
-template <bool VREC, int OCC, int WAVES>
+// BVH (the tree as the world, primary rays): the scene arrays are in leaf ("slot") order, so the binning
+// yields slot lists.  A triangle is hit through the tree iff it passes Triangle::collision_detection
+// (with the direction of its depth: c3 on the hot chain) AND the boxes of its leaf and of all the
+// leaf's ancestors pass AABB::hit; the tile's list is a superset of the first condition, so per
+// sample the staged walk finds every pixel's winner under the tree's tie order (BvhTiles::partner),
+// chain_ok checks that winner's boxes — once per hit pixel, at full lane utilisation — and a
+// winner whose chain fails is excluded for that pixel and the walk repeated (rare).  Tiles with more
+// than 32 survivors (or without a list) and wave-samples off the hot direction chain take the
+// tree itself (bvh_trace).  There is no heavy phase: bin_alloc queues every tile as light.
+template <bool VREC, int OCC, int WAVES, bool BVH = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
-                   TiledWork w, unsigned long long* __restrict__ stats, int dbg_repeat_in) {
+                   TiledWork w, unsigned long long* __restrict__ stats, int dbg_repeat_in, const BvhTiles* __restrict__ bvh) {
     __shared__ unsigned long long best_key[64];   // per pixel: min over the waves of (ordered t, index)
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
@@ -1346,7 +1357,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     unsigned total_heavy = 0;
 #pragma unroll
     for (int c = 0; c < kHeavyClasses; ++c) total_heavy += w.counters[kCtrQueueLen + c];
-    {
+    if (!BVH) {
         unsigned item = blockIdx.x;
         while (item < total_heavy) {
             int c = 0;
@@ -1502,6 +1513,87 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         const int mine1 = (64 + lane < cnt) ? (int)lst[64 + lane] : 0;
         const int n0 = min(cnt, 64);
         Cand cand = {0u, 0u, 0u, 0u};
+        if (BVH && desc.y != 0u) {
+            const BvhTiles& bt = *bvh;
+            BvhView view;
+            view.nodes = bt.nodes;
+            view.n_nodes = bt.n_nodes;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) view.rot[k] = bt.rot[k];
+            const bool store = x < p.nx && ly < p.row_count;
+            const int px = min(x, p.nx - 1), ply = min(ly, p.row_count - 1);   // lanes off the image replay a valid pixel, unstored
+            const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
+            if (!VREC || desc.y == kNoList || cnt > 32) {   // long or missing list: every sample walks the tree
+                render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                    V3 used;
+                    bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
+                });
+                continue;
+            }
+            stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, cnt, lane, px,
+                             global_row(p.row_begin, p.strip_rows, p.strip_step, ply), cand);
+            if (lane < cnt)   // the tree's tie order instead of the slot: smaller wins (larger partner = later leaf, first in its leaf)
+                lent[wave][lane] = (int)(((unsigned)mine0 & kCullSureBit) | (unsigned)(0x7fffffff - bt.partner[mine0 & 0x7fffffff]));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!store) cand.lo = cand.hi = 0u;
+            unsigned bp = 0xffffffffu;
+            if (WAVES <= 8) bp = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
+            render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                const V3 c1 = rot0_exact(view.rot, d1);
+                const V3 c2 = chain_next<true>(view.rot, c1);
+                const V3 c3 = chain_next<true>(view.rot, c2);
+                const V3 c4 = chain_next<true>(view.rot, c3);
+                const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
+                                       fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
+                const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f;
+                if (__builtin_amdgcn_ballot_w64(!hot) != 0ull) {   // off the hot chain (0.01 % of rays): this wave-sample walks the tree
+                    V3 used;
+                    bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
+                    return;
+                }
+                unsigned excl = 0u;
+                for (bool first = true;; first = false) {
+                    int q = -1;
+                    if (first && bp != 0xffffffffu) {
+                        lkey[wave][lane] = ~0ull;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        trace_pairs(lrec[wave], lent[wave], lpairs[wave], bp, lane, [&](int pix) {
+                            return V3{__int_as_float(__builtin_amdgcn_ds_bpermute(pix << 2, __float_as_int(c3.x))),
+                                      __int_as_float(__builtin_amdgcn_ds_bpermute(pix << 2, __float_as_int(c3.y))),
+                                      __int_as_float(__builtin_amdgcn_ds_bpermute(pix << 2, __float_as_int(c3.z)))};
+                        }, lkey[wave]);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const unsigned long long kb = lkey[wave][lane];
+                        q = (kb == ~0ull) ? -1 : (int)(unsigned)(kb & 0xffffffffull);
+                    } else {
+                        Cand rest = cand;
+                        rest.lo &= ~excl;
+                        float tb = FLT_MAX;
+                        trace_candidates(lrec[wave], lent[wave], rest, c3, tb, q);
+                    }
+                    int slot = -1;
+                    bool bad = false;
+                    if (q >= 0) {
+                        slot = bt.partner[0x7fffffff - q];
+                        bad = !chain_ok(bt, slot, o, c1, c2, c3);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+                        hit_idx = slot;
+                        closest = 0.0f;   // not used after the traversal
+                        break;
+                    }
+                    if (bad)   // this pixel's winner is not reachable through the tree: exclude it and look again
+                        for (int k = 0; k < cnt; ++k)
+                            if ((lent[wave][k] & 0x7fffffff) == q) excl |= 1u << k;
+                }
+            });
+            continue;
+        }
         if (VREC && cnt > 0)   // all 64 lanes, before any lane leaves: lanes off the image classify a valid pixel
             stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, n0, lane, min(x, p.nx - 1),
                              global_row(p.row_begin, p.strip_rows, p.strip_step, min(ly, p.row_count - 1)), cand);
@@ -1746,7 +1838,7 @@ hipError_t launch_frame_prepass(const float* d_base, int n_tris, int n_pad, cons
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
-                         hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream) {
+                         hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream, const BvhTiles* d_bvh_tiles) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     if (variant == 0 || d_cls == nullptr || work == nullptr) {
         dim3 block(256);
@@ -1777,7 +1869,8 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::max(1, std::min(atoi(e), 64));
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
 #endif
-    using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int);
+    using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int,
+                             const BvhTiles*);
     ShadeFn fn;
     if (group == 8) {
         occ = (occ == 4) ? 4 : 6;   // 8 waves per SIMD do not fit the LDS of the staged variant
@@ -1788,6 +1881,11 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         occ = (occ == 4) ? 4 : 8;
         fn = vrec ? (occ == 4 ? shade_tiles_kernel<true, 4, 16> : shade_tiles_kernel<true, 8, 16>)
                   : (occ == 4 ? shade_tiles_kernel<false, 4, 16> : shade_tiles_kernel<false, 8, 16>);
+    }
+    if (d_bvh_tiles) {   // the tree as the world: staged light tiles + tree walks, no heavy phase (every tile is queued as light)
+        group = 8;
+        fn = shade_tiles_kernel<true, 6, 8, true>;
+        heavy = -1;      // as unsigned: no tile is heavier
     }
     // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b);
     // the occupancy query is cached per launch context (device + stream), not per host thread
@@ -1810,7 +1908,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)n_blocks), dim3((unsigned)group * 64), 0, stream, p, d_rec, d_cls, n_pad, d_shade_n,
-                       d_state, d_rgb, w, d_stats, dbg_repeat);
+                       d_state, d_rgb, w, d_stats, dbg_repeat, d_bvh_tiles);
     return hipGetLastError();
 }
 
@@ -2036,7 +2134,6 @@ hipError_t launch_assemble_strips(const float* d_parts, long long part_stride, i
     return hipGetLastError();
 }
 
-#include "crt_bvh_kernels.hpp"
 #include "crt_shade_kernels.hpp"
 
 }  // namespace crt

@@ -173,11 +173,12 @@ def assert_same_tree(scene, bvh):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6])
 @pytest.mark.parametrize("name", sorted(BVH_GOLDEN))
 def test_gpu_bvh_matches_golden(gpu, golden_dir, name, variant):
-    """Tree (boxes, structure, leaf order) and frame equal the oracle's, in the hot traversal loop
-    and in both forced general modes; stream 0 is left where the reference leaves it."""
+    """Tree (boxes, structure, leaf order) and frame equal the oracle's: primary rays through the
+    tiled kernels (variant 0: tile lists + the chain of boxes for every pixel's winner), the per-ray
+    tree walk (1) and its two forced general modes (5, 6); stream 0 is left where the reference leaves it."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     nx, ny, spp = int(g["nx"]), int(g["ny"]), int(g["spp"])
     scene, cam = make(BVH_GOLDEN[name](), nx, ny)
@@ -202,7 +203,7 @@ def test_gpu_bvh_random_soup_matches_oracle(gpu, oracle, seed, ntri, nx, ny, spp
     states = oracle.fresh_states(nx, ny)
     bvh = oracle.Bvh(w, states)
     ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
-    for variant in (0, 5, 6):
+    for variant in (0, 1, 5, 6):
         (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
         assert_same_tree(scene, bvh)
         assert np.array_equal(bits(rgb), bits(ref)), variant
@@ -272,7 +273,9 @@ def test_gpu_bvh_strips_and_list_agreement_on_the_bench_mesh(gpu, oracle, tmp_pa
     spp = 2
     scene = api.Scene.from_obj(path, scale=1.0)
     cam = api.init_camera(nx, ny)
-    (rgb,), st_bvh = hip_bvh_frames(gpu, scene, cam, nx, ny, spp)
+    (rgb,), st_bvh = hip_bvh_frames(gpu, scene, cam, nx, ny, spp)                     # tiled kernels + chain of boxes
+    (walk,), st_walk = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=1)        # per-ray tree walk
+    assert np.array_equal(bits(rgb), bits(walk)) and np.array_equal(st_bvh, st_walk)
     st = api.SetCurandState(nx, ny, 0)
     d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
     api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=gpu.cuda.current_stream())
@@ -305,3 +308,42 @@ def test_gpu_bvh_strips_and_list_agreement_on_the_bench_mesh(gpu, oracle, tmp_pa
     ref, _ = oracle.render_bvh(bvh, ocam, nx, ny, spp, states, window=win)
     r0, r1, c0, c1 = win
     assert np.array_equal(bits(rgb[r0:r1, c0:c1]), bits(ref[r0:r1, c0:c1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,seed", [("flat", 31), ("dense", 32), ("sliver", 33)])
+def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind, seed):
+    """The tiled BVH mode against the per-ray tree walk and the oracle where the two conditions of a
+    hit come apart: axis-aligned triangles (flat boxes: passes the triangle test, never the box —
+    every winner is excluded and the next one tried), dense overlapping soups (ties, long lists,
+    tree-walk tiles), slivers (thin boxes at the limit of the slab test)."""
+    rng = np.random.RandomState(seed)
+    if kind == "flat":
+        n = 120
+        c = np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), rng.uniform(-12, -4, n)], axis=-1)
+        tri = c[:, None, :] + rng.uniform(-1.2, 1.2, (n, 3, 3))
+        tri[::2, :, 2] = tri[::2, :1, 2]                      # every other triangle lies in a plane z = const
+        tri[1::4, :, 0] = tri[1::4, :1, 0]                    # some in x = const
+    elif kind == "dense":
+        n = 600
+        c = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(-9, -5, n)], axis=-1)
+        tri = c[:, None, :] + rng.uniform(-1.0, 1.0, (n, 3, 3))
+        tri[50:100] = tri[0:50]                               # coincident duplicates in other leaves
+    else:
+        n = 200
+        c = np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), rng.uniform(-10, -5, n)], axis=-1)
+        tri = c[:, None, :] + rng.uniform(-2.0, 2.0, (n, 3, 3)) * np.array([1.0, 1.0e-4, 1.0])
+    pts = tri.reshape(-1, 3).astype(np.float32)
+    sc = dict(points=pts, idx=np.arange(n * 3, dtype=np.float32).reshape(n, 3), normals=None, index_base=0,
+              camera=dict(lookfrom=(0.0, 0.0, 0.0), lookat=(0.0, 0.0, -1.0), vfov=60.0, aperture=0.0, focus=10.0))
+    nx, ny, spp = 96, 64, 3
+    scene, cam = make(sc, nx, ny)
+    w, ocam = oracle_scene(oracle, sc, nx, ny)
+    states = oracle.fresh_states(nx, ny)
+    bvh = oracle.Bvh(w, states)
+    ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
+    after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+    for variant in (0, 1):
+        (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
+        assert np.array_equal(bits(rgb), bits(ref)), (kind, variant, int((bits(rgb) != bits(ref)).any(axis=2).sum()))
+        assert np.array_equal(st[1:], after[1:]), (kind, variant)
