@@ -257,26 +257,172 @@ __device__ __forceinline__ void bvh_trace(const BvhView& b, const float* __restr
     bvh_walk_general<FAST, PRIMARY>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot, dir_used);
 }
 
-// The boxes of a slot's leaf and of all its ancestors, each with the direction of its depth
-// (hot chain: c1 for the root, c2 for its children, c3 below), as BVHNode::collision_detection
-// meets them on the way down (bvh.h:164).  Used by the tiled kernel's BVH mode for the winner of
-// a pixel: lanes call it independently.
-__device__ __forceinline__ bool chain_ok(const BvhTiles& bt, int slot, V3 o, V3 c1, V3 c2, V3 c3) {
+// ---- the chain of boxes for the tiled kernel's BVH mode ----------------------------------------------
+// A triangle is reached through the tree iff the boxes of its leaf and of all the leaf's ancestors
+// pass AABB::hit for this ray (each with the direction of its depth; on the hot chain c1 for the
+// root, c2 for its children, c3 below).  Most of those boxes are far larger than an 8x8-pixel tile:
+// TileCone bounds the directions of ALL rays of a tile, box_all_hit proves for a box that every
+// such ray passes the slab test with a margin no rounding can eat, and those levels are skipped.
+
+struct TileCone {      // per tile: component-wise bounds of c_k = F^k(d0) over every ray of the tile, k >= 1
+    V3 lo, hi;
+    bool usable;       // false: no bound (degenerate camera geometry): every level is tested
+};
+
+// (u, v) of a tile's rays lie in [x0/nx, (x0+8)/nx] x [y0/ny, (y0+8)/ny] up to rounding; one pixel of margin each way plus
+// the camera's position slack covers the float evaluation of d0.  c_k is d0 / |d0| up to a few ulp.
+__device__ __forceinline__ TileCone tile_cone(const RenderParams& p, int x0, int y0_global) {
+    const CameraPOD& c = p.cam;
+    const float u0 = ((float)x0 - 1.0f) * p.rnx - p.pos_du, u1 = ((float)x0 + 9.0f) * p.rnx + p.pos_du;
+    const float v0 = ((float)y0_global - 1.0f) * p.rny - p.pos_dv, v1 = ((float)y0_global + 9.0f) * p.rny + p.pos_dv;
+    float lo[3], hi[3], mag = 0.0f, len_hi = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float uu = (k & 1) ? u1 : u0, vv = (k & 2) ? v1 : v0;
+        float d[3], l2 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            d[a] = ((c.llc[a] + uu * c.horizontal[a]) + vv * c.vertical[a]) - c.origin[a];
+            lo[a] = fminf(lo[a], d[a]);
+            hi[a] = fmaxf(hi[a], d[a]);
+            l2 += d[a] * d[a];
+        }
+        len_hi = fmaxf(len_hi, sqrtf(l2));
+    }
+    float dc[3], lc2 = 0.0f, var = 0.0f;   // |d0| >= |d0(centre)| - (half extent of the affine map)
+    const float uc = 0.5f * (u0 + u1), vc = 0.5f * (v0 + v1), hu = 0.5f * (u1 - u0), hv = 0.5f * (v1 - v0);
+    float h2 = 0.0f, w2 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        dc[a] = ((c.llc[a] + uc * c.horizontal[a]) + vc * c.vertical[a]) - c.origin[a];
+        lc2 += dc[a] * dc[a];
+        h2 += c.horizontal[a] * c.horizontal[a];
+        w2 += c.vertical[a] * c.vertical[a];
+        mag += fabsf(c.llc[a]) + fabsf(c.horizontal[a]) + fabsf(c.vertical[a]) + fabsf(c.origin[a]);
+    }
+    var = hu * sqrtf(h2) + hv * sqrtf(w2);
+    const float eps = mag * 9.5367431640625e-7f;                     // 2^-20 mag: float evaluation of d0
+    const float len_lo = (sqrtf(lc2) - var) * 0.99999f - 2.0f * eps;
+    len_hi = len_hi * 1.00001f + 2.0f * eps;
+    TileCone t;
+    t.usable = len_lo > 0.5f * len_hi && len_hi < 1.0e30f && len_lo == len_lo;
+    const float r_lo = 1.0f / len_hi, r_hi = 1.0f / fmaxf(len_lo, 1.0e-30f);
+    float o_lo[3], o_hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = lo[a] - eps, h = hi[a] + eps;
+        const float cl = fminf(l * r_lo, l * r_hi), ch = fmaxf(h * r_lo, h * r_hi);
+        o_lo[a] = cl - (1.0e-6f + 1.0e-5f * fabsf(cl));             // c_k vs d0/|d0|: a few ulp; generous
+        o_hi[a] = ch + (1.0e-6f + 1.0e-5f * fabsf(ch));
+    }
+    t.lo = V3{o_lo[0], o_lo[1], o_lo[2]};
+    t.hi = V3{o_hi[0], o_hi[1], o_hi[2]};
+    return t;
+}
+
+// One axis of the conservative slab test: bounds of t_enter (upper) and t_exit (lower) over every direction
+// component in [dlo, dhi].  x0 = min - o, x1 = max - o.  false: no bound for this axis.
+__device__ __forceinline__ bool slab_bounds(float x0, float x1, float dlo, float dhi, float& enter_up, float& exit_lo) {
+    if (dlo > 1.0e-4f) {                 // all directions positive: enter = x0 / d, exit = x1 / d, monotone in d
+        enter_up = fmaxf(x0 / dlo, x0 / dhi);
+        exit_lo = fminf(x1 / dlo, x1 / dhi);
+        return true;
+    }
+    if (dhi < -1.0e-4f) {                // all negative: enter = x1 / d, exit = x0 / d
+        enter_up = fmaxf(x1 / dlo, x1 / dhi);
+        exit_lo = fminf(x0 / dlo, x0 / dhi);
+        return true;
+    }
+    // The interval touches 0: the origin must lie strictly inside the slab; then enter < 0 < exit for either sign
+    // (and -inf / +inf for a zero component), the extremes being at the interval's ends.
+    const float m = 1.0e-5f * (fabsf(x0) + fabsf(x1)) + 1.0e-30f;
+    if (!(x0 < -m && x1 > m)) return false;
+    enter_up = -1.0e-30f;
+    exit_lo = 3.0e38f;
+    if (dhi > 0.0f) { exit_lo = fminf(exit_lo, x1 / dhi); }
+    if (dlo < 0.0f) { exit_lo = fminf(exit_lo, x0 / dlo); }
+    return true;
+}
+
+// Every ray of the tile (directions within the cone, origin o) passes AABB::hit on this box, with a relative
+// margin of 1e-4 on the slab parameters — four orders of magnitude above the rounding of the per-ray test.
+__device__ __forceinline__ bool box_all_hit(float4 n0, float4 n1, V3 o, const TileCone& t) {
+    if (!t.usable) return false;
+    float ex, lx, ey, ly, ez, lz;
+    if (!slab_bounds(n0.x - o.x, n0.w - o.x, t.lo.x, t.hi.x, ex, lx)) return false;
+    if (!slab_bounds(n0.y - o.y, n1.x - o.y, t.lo.y, t.hi.y, ey, ly)) return false;
+    if (!slab_bounds(n0.z - o.z, n1.y - o.z, t.lo.z, t.hi.z, ez, lz)) return false;
+    const float enter = fmaxf(fmaxf(ex, ey), fmaxf(ez, 0.001f));
+    const float leave = fminf(fminf(lx, ly), lz);
+    const float margin = 1.0e-4f * (fabsf(enter) + fabsf(leave)) + 1.0e-6f;
+    return leave - enter > margin && leave < 1.0e30f;   // NaN anywhere -> false
+}
+
+constexpr int kChainBatch = 8;   // boxes tested per round of loads in chain_ok
+
+// The chain test for one lane's winner `slot`: levels [first_level, depth] of its path (the levels above are
+// proven for the whole tile).  Loads come in rounds: the path's node indices, then up to kChainBatch nodes at once.
+__device__ __forceinline__ bool chain_ok(const BvhTiles& bt, int slot, int tile_first_level, const int* __restrict__ tile_path, V3 o, V3 c1,
+                                         V3 c2, V3 c3) {
     const int info = bt.slot_leaf[slot];
     const int ord = info & 0xffffff, depth = (info >> 24) & 31;
     const int* __restrict__ path = bt.anc + (size_t)ord * bt.anc_stride;
-    const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
-    for (int k = depth; k >= 0; --k) {   // leaf first: small boxes fail first
-        const int node = path[k];
-        const float4 n0 = bt.nodes[2 * (size_t)node], n1 = bt.nodes[2 * (size_t)node + 1];
-        V3 d = c3, y = y3;
-        if (k < 2) {
-            d = k == 0 ? c1 : c2;
-            y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
-        }
-        if (!box_hit_fast(n0, n1, o, d, y)) return false;
+    // the first level to test: where this path leaves the tile's reference path, or the reference's first unproven level
+    int first = tile_first_level;
+    for (int k = 0; k < tile_first_level && k <= depth; k += 4) {
+        const int4 ids = *reinterpret_cast<const int4*>(path + k);
+        const int4 ref = *reinterpret_cast<const int4*>(tile_path + k);
+        int d = 4;
+        if (ids.w != ref.w) d = 3;
+        if (ids.z != ref.z) d = 2;
+        if (ids.y != ref.y) d = 1;
+        if (ids.x != ref.x) d = 0;
+        if (d < 4) { first = min(first, k + d); break; }
     }
-    return true;
+    const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
+    bool ok = true;
+    for (int k0 = first; k0 <= depth && ok; k0 += kChainBatch) {
+        int node[kChainBatch];
+        float4 a[kChainBatch], b[kChainBatch];
+#pragma unroll
+        for (int j = 0; j < kChainBatch; ++j) node[j] = path[min(k0 + j, depth)];
+#pragma unroll
+        for (int j = 0; j < kChainBatch; ++j) {
+            a[j] = bt.nodes[2 * (size_t)node[j]];
+            b[j] = bt.nodes[2 * (size_t)node[j] + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < kChainBatch; ++j) {
+            const int k = min(k0 + j, depth);
+            V3 d = c3, y = y3;
+            if (k < 2) {
+                d = k == 0 ? c1 : c2;
+                y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
+            }
+            ok = ok && box_hit_fast(a[j], b[j], o, d, y);
+        }
+    }
+    return ok;
+}
+
+// Per tile, wave-uniform: the reference path = the path of `slot0` (copied to tile_path, LDS), and the first of its
+// levels whose box is not proven hit for every ray of the tile.
+__device__ __forceinline__ int tile_reference_path(const BvhTiles& bt, int slot0, V3 o, const TileCone& cone, int* __restrict__ tile_path, int lane) {
+    const int info = bt.slot_leaf[slot0];
+    const int ord = info & 0xffffff, depth = (info >> 24) & 31;
+    const int* __restrict__ path = bt.anc + (size_t)ord * bt.anc_stride;
+    if (lane < 32) tile_path[lane] = (lane <= depth) ? path[lane] : -1;
+    int first = depth + 1;
+    for (int k = 0; k <= depth; ++k) {   // uniform addresses: scalar loads
+        const int node = path[k];
+        if (!box_all_hit(bt.nodes[2 * (size_t)node], bt.nodes[2 * (size_t)node + 1], o, cone)) { first = k; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return first;
 }
 
 // The render kernel with world = the BVH: lane = pixel, wavefront = 8x8 tile, block = 16x16.

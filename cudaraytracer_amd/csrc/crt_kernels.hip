@@ -1343,6 +1343,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     constexpr int kPairCap = (VREC && WAVES <= 8) ? 512 : 1;
     __shared__ unsigned short lpairs[(VREC && WAVES <= 8) ? WAVES : 1][kPairCap];   // (pixel | entry << 6 | cull-sure << 12)
     __shared__ unsigned long long lkey[(VREC && WAVES <= 8) ? WAVES : 1][64];       // per pixel: min (ordered t, index)
+    __shared__ __attribute__((aligned(16))) int lpath[BVH ? WAVES : 1][32];        // BVH mode: node indices of the tile's reference path
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1523,7 +1524,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool store = x < p.nx && ly < p.row_count;
             const int px = min(x, p.nx - 1), ply = min(ly, p.row_count - 1);   // lanes off the image replay a valid pixel, unstored
             const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-            if (!VREC || desc.y == kNoList || cnt > 32) {   // long or missing list: every sample walks the tree
+            if (!VREC || desc.y == kNoList || cnt > 64) {   // long or missing list: every sample walks the tree
                 render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     V3 used;
                     bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
@@ -1540,6 +1541,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             if (!store) cand.lo = cand.hi = 0u;
             unsigned bp = 0xffffffffu;
             if (WAVES <= 8) bp = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
+            // levels of the tree proven hit for every ray of this tile (along the first entry's path)
+            const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
+            const int first_level = __builtin_amdgcn_readfirstlane(
+                tile_reference_path(bt, __builtin_amdgcn_readfirstlane(mine0 & 0x7fffffff), o, cone, lpath[wave], lane));
             render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                 const V3 c1 = rot0_exact(view.rot, d1);
                 const V3 c2 = chain_next<true>(view.rot, c1);
@@ -1553,7 +1558,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
                     return;
                 }
-                unsigned excl = 0u;
+                unsigned excl = 0u, excl_hi = 0u;
                 for (bool first = true;; first = false) {
                     int q = -1;
                     if (first && bp != 0xffffffffu) {
@@ -1573,6 +1578,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     } else {
                         Cand rest = cand;
                         rest.lo &= ~excl;
+                        rest.hi &= ~excl_hi;
                         float tb = FLT_MAX;
                         trace_candidates(lrec[wave], lent[wave], rest, c3, tb, q);
                     }
@@ -1580,7 +1586,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     bool bad = false;
                     if (q >= 0) {
                         slot = bt.partner[0x7fffffff - q];
-                        bad = !chain_ok(bt, slot, o, c1, c2, c3);
+                        bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
                     }
                     if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
                         hit_idx = slot;
@@ -1589,7 +1595,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     }
                     if (bad)   // this pixel's winner is not reachable through the tree: exclude it and look again
                         for (int k = 0; k < cnt; ++k)
-                            if ((lent[wave][k] & 0x7fffffff) == q) excl |= 1u << k;
+                            if ((lent[wave][k] & 0x7fffffff) == q) {
+                                if (k < 32) excl |= 1u << k;
+                                else excl_hi |= 1u << (k - 32);
+                            }
                 }
             });
             continue;
@@ -1884,7 +1893,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     }
     if (d_bvh_tiles) {   // the tree as the world: staged light tiles + tree walks, no heavy phase (every tile is queued as light)
         group = 8;
-        fn = shade_tiles_kernel<true, 6, 8, true>;
+        fn = shade_tiles_kernel<true, 4, 8, true>;   // 128 VGPRs: the chain test holds a batch of boxes
         heavy = -1;      // as unsigned: no tile is heavier
     }
     // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b);
