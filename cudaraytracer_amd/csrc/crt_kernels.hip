@@ -1524,10 +1524,96 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool store = x < p.nx && ly < p.row_count;
             const int px = min(x, p.nx - 1), ply = min(ly, p.row_count - 1);   // lanes off the image replay a valid pixel, unstored
             const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-            if (!VREC || desc.y == kNoList || cnt > 64) {   // long or missing list: every sample walks the tree
+            if (!VREC || desc.y == kNoList || cnt > 4 * 64) {   // very long or missing list: every sample walks the tree
                 render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     V3 used;
                     bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
+                });
+                continue;
+            }
+            if (cnt > 64) {
+                // 65..256 entries (the heavy tiles of the list world): chunks of 64.  The candidate masks of every
+                // chunk are found once per tile; per sample each chunk's exact records pass through the staging
+                // area again (one 64-B load per lane) and the winner is carried from chunk to chunk.
+                const int n_chunks = (cnt + 63) / 64;
+                const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ply);
+                Cand cc[4];
+                int ent_c[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    cc[c] = Cand{0u, 0u, 0u, 0u};
+                    ent_c[c] = 0;
+                    if (c < n_chunks) {
+                        const int n = min(64, cnt - 64 * c);
+                        ent_c[c] = (lane < n) ? (int)lst[64 * c + lane] : 0;
+                        stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, ent_c[c], n, lane, px, gy, cc[c]);
+                        if (!store) cc[c].lo = cc[c].hi = 0u;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
+                const int first_level = __builtin_amdgcn_readfirstlane(
+                    tile_reference_path(bt, __builtin_amdgcn_readfirstlane(ent_c[0] & 0x7fffffff), o, cone, lpath[wave], lane));
+                int q_c[4];   // tie order of this lane's entry in every chunk
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    q_c[c] = (c < n_chunks && lane < min(64, cnt - 64 * c))
+                                 ? (int)(((unsigned)ent_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bt.partner[ent_c[c] & 0x7fffffff])) : 0;
+                render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                    const V3 c1 = rot0_exact(view.rot, d1);
+                    const V3 c2 = chain_next<true>(view.rot, c1);
+                    const V3 c3 = chain_next<true>(view.rot, c2);
+                    const V3 c4 = chain_next<true>(view.rot, c3);
+                    const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
+                                           fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
+                    const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f;
+                    if (__builtin_amdgcn_ballot_w64(!hot) != 0ull) {
+                        V3 used;
+                        bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
+                        return;
+                    }
+                    unsigned ex[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+                    for (;;) {
+                        float tb = FLT_MAX;
+                        int q = -1;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (c >= n_chunks) continue;
+                            __builtin_amdgcn_wave_barrier();   // the previous chunk's reads are done
+                            if (lane < min(64, cnt - 64 * c)) {
+                                const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(ent_c[c] & 0x7fffffff) * kRecFloats);
+                                lrec[wave][0][lane] = r[0]; lrec[wave][1][lane] = r[1]; lrec[wave][2][lane] = r[2]; lrec[wave][3][lane] = r[3];
+                                lent[wave][lane] = q_c[c];
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            Cand rest = cc[c];
+                            rest.lo &= ~ex[c][0];
+                            rest.hi &= ~ex[c][1];
+                            trace_candidates(lrec[wave], lent[wave], rest, c3, tb, q);
+                        }
+                        int slot = -1;
+                        bool bad = false;
+                        if (q >= 0) {
+                            slot = bt.partner[0x7fffffff - q];
+                            bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
+                            hit_idx = slot;
+                            closest = 0.0f;
+                            break;
+                        }
+                        if (bad)   // exclude the unreachable winner for this pixel: find its position in the tile's list
+                            for (int k = 0; k < cnt; ++k)
+                                if ((int)(lst[k] & 0x7fffffffu) == slot) {
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c)   // constant indices: the masks stay in registers
+#pragma unroll
+                                        for (int h = 0; h < 2; ++h)
+                                            if ((k >> 6) == c && ((k >> 5) & 1) == h) ex[c][h] |= 1u << (k & 31);
+                                }
+                    }
                 });
                 continue;
             }
