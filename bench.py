@@ -224,6 +224,26 @@ def main():
                    "tiles_with_geometry_frac": 1.0 - st_n[8] / max(st_n[4], 1),
                    "tile_survivors_sum": st_n[5], "tile_survivors_max": st_n[6]}
 
+    # The same frame through the BVH world (the reference's shipped configuration, kernel.cu:97): not the
+    # headline metric (north_star names the list path), reported beside it.
+    bvh_world = None
+    if rank == 0 and world == 1 and tiled:
+        st_b = api.SetCurandState(NX, NY, 0)
+        t1 = time.perf_counter()
+        api.create_BVHfromList(scene, st_b)
+        build_s = time.perf_counter() - t1
+        buf = torch.empty(NX * NY * 3, dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            api.render_rows(scene, camera, st_b, NX, NY, args.spp, 0, NY, buf, stream=stream, bvh=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            api.render_rows(scene, camera, st_b, NX, NY, args.spp, 0, NY, buf, stream=stream, bvh=True)
+        torch.cuda.synchronize()
+        ms_b = (time.perf_counter() - t1) / 10 * 1e3
+        bvh_world = {"what": "same frame, world = BVHNode tree (crt_render_rows_bvh): tiled kernels + chain of boxes per winner",
+                     "ms_per_frame": ms_b, "Mrays/s": NX * NY * args.spp / ms_b / 1e3, "host_build_s": build_s}
+
     if rank == 0:
         rays = NX * NY * args.spp * args.steps
         value = rays / elapsed / 1e6
@@ -298,6 +318,7 @@ def main():
             "kernels": kernels,
             "survivors": survivors,
             "screen_filling_variant": filling,
+            "bvh_world": bvh_world,
         }
         if world == 1 and not args.no_cpu_baseline:
             base, win, cs, ref = cpu_baseline(obj_path)

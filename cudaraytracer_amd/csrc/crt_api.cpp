@@ -830,13 +830,13 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         // Primary rays ride the tiled kernels (binning over the slot-ordered triangles, the tree only for every
         // pixel's winner: shade_tiles_kernel<.., BVH>) whenever the list world's tiled variant is eligible and
         // the fast arithmetic holds; variant 1 (and the test hooks 5, 6) select the per-ray tree walk.
-        if (fast && tiled_ok && (g_variant == 0 || g_variant == 2)) {
+        if (fast && tiled_ok && (g_variant == 0 || g_variant == 2 || g_variant == 7)) {
             int rc = ensure_workspace(cx, nx, row_count);
             if (rc != CRT_OK) return rc;
             HIP_TRY(crt::launch_frame_prepass(scene->bvh->d_base_slots, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
             HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, 1, &cx.w,
                                        cx.n_cus, true, g_d_stats, cx.ev_mid, &cx.cache_bvh, true, stream,
-                                       static_cast<const crt::BvhTiles*>(scene->bvh->d_tiles_view)));
+                                       static_cast<const crt::BvhTiles*>(scene->bvh->d_tiles_view), g_variant == 7));
             cx.ev_has_mid = true;
             HIP_TRY(hipEventRecord(cx.ev_stop, stream));
             cx.ev_valid = true;

@@ -407,6 +407,50 @@ __device__ __forceinline__ bool chain_ok(const BvhTiles& bt, int slot, int tile_
     return ok;
 }
 
+// The same for a lane off the hot chain (its direction chain has not settled by c3, or a component is tiny): every
+// level with the chain element of its depth, literal IEEE slab test, no level skipped.  Per lane, no wave votes.
+__device__ __forceinline__ bool chain_ok_general(const BvhTiles& bt, int slot, V3 o, V3 c1, V3 c2, V3 c3, V3 c4, int mode) {
+    const int info = bt.slot_leaf[slot];
+    const int ord = info & 0xffffff, depth = (info >> 24) & 31;
+    const int* __restrict__ path = bt.anc + (size_t)ord * bt.anc_stride;
+    for (int k = 0; k <= depth; ++k) {
+        const int node = path[k];
+        if (!box_hit_ieee(bt.nodes[2 * (size_t)node], bt.nodes[2 * (size_t)node + 1], o, chain_at<true>(bt.rot, k + 1, c1, c2, c3, c4, mode)))
+            return false;
+    }
+    return true;
+}
+
+// The winner of one lane off the hot chain among the entries `lst[0..cnt)` whose bit is set in its candidate masks
+// (mask word j covers entries 32 j .. 32 j + 31), minus the excluded ones: each entry is tested with the chain element of
+// ITS leaf's depth (F^(depth + 3)), from the exact record in global memory.  Returns the tie key q (or -1) and the slot.
+__device__ __forceinline__ int general_winner(const BvhTiles& bt, const float* __restrict__ rec, const uint32_t* __restrict__ lst, int cnt,
+                                              const unsigned* masks, const unsigned* excl, int n_words, V3 o, V3 c1, V3 c2, V3 c3, V3 c4,
+                                              int mode, int& slot_out) {
+    float best_t = FLT_MAX;
+    int best_q = -1, best_slot = -1;
+    for (int j = 0; j < n_words; ++j) {
+        unsigned m = masks[j] & ~excl[j];
+        while (m != 0u) {
+            const int k = 32 * j + __builtin_ctz(m);
+            m &= m - 1u;
+            if (k >= cnt) break;
+            const int slot = (int)(lst[k] & 0x7fffffffu);
+            const int depth = (bt.slot_leaf[slot] >> 24) & 31;
+            float t;
+            if (!tri_hit_lane<true, true>(rec, slot, o, chain_at<true>(bt.rot, depth + 3, c1, c2, c3, c4, mode), t)) continue;
+            const int q = 0x7fffffff - bt.partner[slot];
+            if (t < best_t || (t == best_t && q < best_q)) {
+                best_t = t;
+                best_q = q;
+                best_slot = slot;
+            }
+        }
+    }
+    slot_out = best_slot;
+    return best_q;
+}
+
 // Per tile, wave-uniform: the reference path = the path of `slot0` (copied to tile_path, LDS), and the first of its
 // levels whose box is not proven hit for every ray of the tile.
 __device__ __forceinline__ int tile_reference_path(const BvhTiles& bt, int slot0, V3 o, const TileCone& cone, int* __restrict__ tile_path, int lane) {

@@ -120,7 +120,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
                          hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream,
-                         const BvhTiles* d_bvh_tiles = nullptr);
+                         const BvhTiles* d_bvh_tiles = nullptr, bool bvh_force_general = false);
 // The per-frame prepass of the tiled variant in ONE launch: exact records (tri_prepass) + classification
 // records (cls_prepass) + zeroing of this frame's binning scratch (w.tile_count, w.counters);
 // launch_render is then called with prezeroed = true.

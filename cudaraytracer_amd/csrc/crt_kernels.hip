@@ -1566,11 +1566,23 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     const V3 c4 = chain_next<true>(view.rot, c3);
                     const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
                                            fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
-                    const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f;
-                    if (__builtin_amdgcn_ballot_w64(!hot) != 0ull) {
-                        V3 used;
-                        bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
-                        return;
+                    const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f && dbg_repeat_in != -77;   // -77: test hook, every lane takes the general path
+                    if (!hot) {   // off the hot chain (0.01 % of rays): this lane alone, with the chain element of every depth
+                        const V3 c5 = rot0(view.rot, unit_vector(c4));
+                        const int mode = same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2);
+                        const unsigned masks[8] = {cc[0].lo, cc[0].hi, cc[1].lo, cc[1].hi, cc[2].lo, cc[2].hi, cc[3].lo, cc[3].hi};
+                        unsigned gex[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                        for (;;) {
+                            int slot = -1;
+                            const int q = general_winner(bt, rec, lst, cnt, masks, gex, 8, o, c1, c2, c3, c4, mode, slot);
+                            if (q < 0 || chain_ok_general(bt, slot, o, c1, c2, c3, c4, mode)) { hit_idx = slot; break; }
+                            for (int k = 0; k < cnt; ++k)
+                                if ((int)(lst[k] & 0x7fffffffu) == slot) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j)
+                                        if ((k >> 5) == j) gex[j] |= 1u << (k & 31);
+                                }
+                        }
                     }
                     unsigned ex[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
                     for (;;) {
@@ -1595,12 +1607,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         }
                         int slot = -1;
                         bool bad = false;
-                        if (q >= 0) {
+                        if (q >= 0 && hot) {
                             slot = bt.partner[0x7fffffff - q];
                             bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
                         }
                         if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
-                            hit_idx = slot;
+                            if (hot) hit_idx = slot;
                             closest = 0.0f;
                             break;
                         }
@@ -1638,11 +1650,22 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 const V3 c4 = chain_next<true>(view.rot, c3);
                 const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
                                        fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
-                const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f;
-                if (__builtin_amdgcn_ballot_w64(!hot) != 0ull) {   // off the hot chain (0.01 % of rays): this wave-sample walks the tree
-                    V3 used;
-                    bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
-                    return;
+                const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f && dbg_repeat_in != -77;   // -77: test hook, every lane takes the general path
+                if (!hot) {   // off the hot chain (0.01 % of rays): this lane alone, with the chain element of every depth
+                    const V3 c5 = rot0(view.rot, unit_vector(c4));
+                    const int mode = same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2);
+                    const unsigned masks[2] = {cand.lo, cand.hi};
+                    unsigned gex[2] = {0u, 0u};
+                    for (;;) {
+                        int slot = -1;
+                        const int q = general_winner(bt, rec, lst, cnt, masks, gex, 2, o, c1, c2, c3, c4, mode, slot);
+                        if (q < 0 || chain_ok_general(bt, slot, o, c1, c2, c3, c4, mode)) { hit_idx = slot; break; }
+                        for (int k = 0; k < cnt; ++k)
+                            if ((int)(lst[k] & 0x7fffffffu) == slot) {
+                                if (k < 32) gex[0] |= 1u << k;
+                                else gex[1] |= 1u << (k - 32);
+                            }
+                    }
                 }
                 unsigned excl = 0u, excl_hi = 0u;
                 for (bool first = true;; first = false) {
@@ -1670,12 +1693,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     }
                     int slot = -1;
                     bool bad = false;
-                    if (q >= 0) {
+                    if (q >= 0 && hot) {
                         slot = bt.partner[0x7fffffff - q];
                         bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
                     }
                     if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
-                        hit_idx = slot;
+                        if (hot) hit_idx = slot;
                         closest = 0.0f;   // not used after the traversal
                         break;
                     }
@@ -1933,7 +1956,8 @@ hipError_t launch_frame_prepass(const float* d_base, int n_tris, int n_pad, cons
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
-                         hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream, const BvhTiles* d_bvh_tiles) {
+                         hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream, const BvhTiles* d_bvh_tiles,
+                         bool bvh_force_general) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     if (variant == 0 || d_cls == nullptr || work == nullptr) {
         dim3 block(256);
@@ -1981,6 +2005,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         group = 8;
         fn = shade_tiles_kernel<true, 4, 8, true>;   // 128 VGPRs: the chain test holds a batch of boxes
         heavy = -1;      // as unsigned: no tile is heavier
+        if (bvh_force_general) dbg_repeat = -77;
     }
     // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b);
     // the occupancy query is cached per launch context (device + stream), not per host thread

@@ -173,7 +173,7 @@ def assert_same_tree(scene, bvh):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7])
 @pytest.mark.parametrize("name", sorted(BVH_GOLDEN))
 def test_gpu_bvh_matches_golden(gpu, golden_dir, name, variant):
     """Tree (boxes, structure, leaf order) and frame equal the oracle's: primary rays through the
@@ -203,7 +203,7 @@ def test_gpu_bvh_random_soup_matches_oracle(gpu, oracle, seed, ntri, nx, ny, spp
     states = oracle.fresh_states(nx, ny)
     bvh = oracle.Bvh(w, states)
     ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
-    for variant in (0, 1, 5, 6):
+    for variant in (0, 1, 5, 6, 7):
         (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
         assert_same_tree(scene, bvh)
         assert np.array_equal(bits(rgb), bits(ref)), variant
@@ -343,7 +343,7 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
     bvh = oracle.Bvh(w, states)
     ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
     after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
-    for variant in (0, 1):
+    for variant in (0, 1, 7):
         (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
         assert np.array_equal(bits(rgb), bits(ref)), (kind, variant, int((bits(rgb) != bits(ref)).any(axis=2).sum()))
         assert np.array_equal(st[1:], after[1:]), (kind, variant)

@@ -33,6 +33,11 @@ for bvh in (True, False):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
     print("%s %dx%dx%d %s world: %.3f ms/frame, %.0f Mrays/s" % (name, nx, ny, spp, "BVH " if bvh else "list", ms, nx * ny * spp / ms / 1e3))
+api.tiled_stats(True)
+api.render_rows(scene, cam, st, nx, ny, 1, 0, ny, d, stream=s, bvh=True)
+torch.cuda.synchronize()
+o = api.tiled_stats(False)
+print("%s tile lists (slot order): sum %d, max %d, histogram (bucket b: 2^(b-1) <= n < 2^b) %s" % (name, o[5], o[6], o[8:20]))
 t0 = time.perf_counter()
 for _ in range(10):
     api.Update_BVH(scene, s)
