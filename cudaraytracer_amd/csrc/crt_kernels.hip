@@ -1524,7 +1524,54 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool store = x < p.nx && ly < p.row_count;
             const int px = min(x, p.nx - 1), ply = min(ly, p.row_count - 1);   // lanes off the image replay a valid pixel, unstored
             const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-            if (!VREC || desc.y == kNoList || cnt > 4 * 64) {   // very long or missing list: every sample walks the tree
+            if (VREC && desc.y != kNoList && cnt > 4 * 64) {
+                // Very long lists (the poles of a lat-long mesh at 4K: up to ~2000 entries): every sample passes ALL chunks
+                // through the staging area, candidate masks included (no room to keep them); a lane off the hot chain or
+                // with an unreachable winner walks the tree for that sample.
+                const int n_chunks = (cnt + 63) / 64;
+                const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ply);
+                const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
+                const int first_level = __builtin_amdgcn_readfirstlane(
+                    tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[wave], lane));
+                render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                    const V3 c1 = rot0_exact(view.rot, d1);
+                    const V3 c2 = chain_next<true>(view.rot, c1);
+                    const V3 c3 = chain_next<true>(view.rot, c2);
+                    const V3 c4 = chain_next<true>(view.rot, c3);
+                    const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
+                                           fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
+                    const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f && dbg_repeat_in != -77;
+                    float tb = FLT_MAX;
+                    int q = -1;
+                    for (int c = 0; c < n_chunks; ++c) {
+                        const int n = min(64, cnt - 64 * c);
+                        const int e = (lane < n) ? (int)lst[64 * c + lane] : 0;
+                        Cand cd;
+                        stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, e, n, lane, px, gy, cd);
+                        if (lane < n) lent[wave][lane] = (int)(((unsigned)e & kCullSureBit) | (unsigned)(0x7fffffff - bt.partner[e & 0x7fffffff]));
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (!store) cd.lo = cd.hi = 0u;
+                        trace_candidates(lrec[wave], lent[wave], cd, c3, tb, q);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    int slot = -1;
+                    bool walk_it = !hot;
+                    if (hot && q >= 0) {
+                        slot = bt.partner[0x7fffffff - q];
+                        walk_it = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
+                    }
+                    hit_idx = slot;
+                    if (walk_it) {   // per lane (the walk's votes are taken among the lanes that are here)
+                        V3 used;
+                        bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
+                    }
+                    closest = 0.0f;
+                });
+                continue;
+            }
+            if (!VREC || desc.y == kNoList) {   // no list (pool overflow): every sample walks the tree
                 render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     V3 used;
                     bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);

@@ -311,7 +311,7 @@ def test_gpu_bvh_strips_and_list_agreement_on_the_bench_mesh(gpu, oracle, tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,seed", [("flat", 31), ("dense", 32), ("sliver", 33)])
+@pytest.mark.parametrize("kind,seed", [("flat", 31), ("dense", 32), ("sliver", 33), ("pile", 34)])
 def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind, seed):
     """The tiled BVH mode against the per-ray tree walk and the oracle where the two conditions of a
     hit come apart: axis-aligned triangles (flat boxes: passes the triangle test, never the box —
@@ -329,6 +329,10 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
         c = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(-9, -5, n)], axis=-1)
         tri = c[:, None, :] + rng.uniform(-1.0, 1.0, (n, 3, 3))
         tri[50:100] = tri[0:50]                               # coincident duplicates in other leaves
+    elif kind == "pile":                                       # > 256 entries in the central tiles: the restaging paths
+        n = 2500
+        c = np.stack([rng.uniform(-0.6, 0.6, n), rng.uniform(-0.6, 0.6, n), rng.uniform(-9, -5, n)], axis=-1)
+        tri = c[:, None, :] + rng.uniform(-0.5, 0.5, (n, 3, 3))
     else:
         n = 200
         c = np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), rng.uniform(-10, -5, n)], axis=-1)
