@@ -1344,6 +1344,11 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     __shared__ unsigned short lpairs[(VREC && WAVES <= 8) ? WAVES : 1][kPairCap];   // (pixel | entry << 6 | cull-sure << 12)
     __shared__ unsigned long long lkey[(VREC && WAVES <= 8) ? WAVES : 1][64];       // per pixel: min (ordered t, index)
     __shared__ __attribute__((aligned(16))) int lpath[BVH ? WAVES : 1][32];        // BVH mode: node indices of the tile's reference path
+    // BVH mode, staged tiles: per list entry its slot, (leaf depth | first level to test << 8 | 1 << 16 when more than
+    // kChainBatch levels remain), and the node indices of those levels — the chain test then needs ONE round of loads
+    __shared__ int lslot[BVH ? WAVES : 1][BVH ? 64 : 1];
+    __shared__ int linfo[BVH ? WAVES : 1][BVH ? 64 : 1];
+    __shared__ __attribute__((aligned(16))) int lnodes[BVH ? WAVES : 1][BVH ? 64 : 1][kChainBatch];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1678,18 +1683,42 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             }
             stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, cnt, lane, px,
                              global_row(p.row_begin, p.strip_rows, p.strip_step, ply), cand);
-            if (lane < cnt)   // the tree's tie order instead of the slot: smaller wins (larger partner = later leaf, first in its leaf)
-                lent[wave][lane] = (int)(((unsigned)mine0 & kCullSureBit) | (unsigned)(0x7fffffff - bt.partner[mine0 & 0x7fffffff]));
+            // levels of the tree proven hit for every ray of this tile (along the first entry's path)
+            const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
+            const int first_level = __builtin_amdgcn_readfirstlane(
+                tile_reference_path(bt, __builtin_amdgcn_readfirstlane(mine0 & 0x7fffffff), o, cone, lpath[wave], lane));
+            if (lane < cnt) {
+                // The tree's tie order instead of the slot — smaller wins (larger partner = later leaf, first in its leaf) —
+                // with the entry's position in the low 6 bits, so the winner's staged data is one LDS read away.
+                const int slot = mine0 & 0x7fffffff;
+                lent[wave][lane] = (int)(((unsigned)mine0 & kCullSureBit) | ((unsigned)(0xffffff - bt.partner[slot]) << 6) | (unsigned)lane);
+                const int info = bt.slot_leaf[slot];
+                const int depth = (info >> 24) & 31;
+                const int* __restrict__ path = bt.anc + (size_t)(info & 0xffffff) * bt.anc_stride;
+                int first_k = first_level;   // where this entry's path leaves the reference path, if earlier
+                for (int k = 0; k < first_level && k <= depth; k += 4) {
+                    const int4 ids = *reinterpret_cast<const int4*>(path + k);
+                    const int4 ref = *reinterpret_cast<const int4*>(&lpath[wave][k]);
+                    int d = 4;
+                    if (ids.w != ref.w) d = 3;
+                    if (ids.z != ref.z) d = 2;
+                    if (ids.y != ref.y) d = 1;
+                    if (ids.x != ref.x) d = 0;
+                    if (d < 4) { first_k = min(first_k, k + d); break; }
+                }
+                first_k = min(first_k, depth);   // the leaf's own box is always tested
+                const int n_lv = depth - first_k + 1;
+                lslot[wave][lane] = slot;
+                linfo[wave][lane] = depth | (first_k << 8) | ((n_lv > kChainBatch) ? (1 << 16) : 0);
+#pragma unroll
+                for (int j = 0; j < kChainBatch; ++j) lnodes[wave][lane][j] = path[min(first_k + j, depth)];
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (!store) cand.lo = cand.hi = 0u;
             unsigned bp = 0xffffffffu;
             if (WAVES <= 8) bp = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
-            // levels of the tree proven hit for every ray of this tile (along the first entry's path)
-            const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
-            const int first_level = __builtin_amdgcn_readfirstlane(
-                tile_reference_path(bt, __builtin_amdgcn_readfirstlane(mine0 & 0x7fffffff), o, cone, lpath[wave], lane));
             render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                 const V3 c1 = rot0_exact(view.rot, d1);
                 const V3 c2 = chain_next<true>(view.rot, c1);
@@ -1740,21 +1769,47 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     }
                     int slot = -1;
                     bool bad = false;
+                    const int kw = q & 63;   // the winner's position in the staged list
                     if (q >= 0 && hot) {
-                        slot = bt.partner[0x7fffffff - q];
-                        bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
+                        slot = lslot[wave][kw];
+                        const int info = linfo[wave][kw];
+                        if (info >> 16) {   // more levels than one batch: the general routine (global loads)
+                            bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
+                        } else {
+                            const int depth = info & 31, first_k = (info >> 8) & 31;
+                            int node[kChainBatch];
+                            float4 na[kChainBatch], nb[kChainBatch];
+#pragma unroll
+                            for (int j = 0; j < kChainBatch; ++j) node[j] = lnodes[wave][kw][j];
+#pragma unroll
+                            for (int j = 0; j < kChainBatch; ++j) {
+                                na[j] = bt.nodes[2 * (size_t)node[j]];
+                                nb[j] = bt.nodes[2 * (size_t)node[j] + 1];
+                            }
+                            const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
+                            bool ok = true;
+#pragma unroll
+                            for (int j = 0; j < kChainBatch; ++j) {
+                                const int lv = min(first_k + j, depth);
+                                V3 d = c3, y = y3;
+                                if (lv < 2) {
+                                    d = lv == 0 ? c1 : c2;
+                                    y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
+                                }
+                                ok = ok && box_hit_fast(na[j], nb[j], o, d, y);
+                            }
+                            bad = !ok;
+                        }
                     }
                     if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
                         if (hot) hit_idx = slot;
                         closest = 0.0f;   // not used after the traversal
                         break;
                     }
-                    if (bad)   // this pixel's winner is not reachable through the tree: exclude it and look again
-                        for (int k = 0; k < cnt; ++k)
-                            if ((lent[wave][k] & 0x7fffffff) == q) {
-                                if (k < 32) excl |= 1u << k;
-                                else excl_hi |= 1u << (k - 32);
-                            }
+                    if (bad) {   // this pixel's winner is not reachable through the tree: exclude it and look again
+                        if (kw < 32) excl |= 1u << kw;
+                        else excl_hi |= 1u << (kw - 32);
+                    }
                 }
             });
             continue;
