@@ -360,7 +360,10 @@ __device__ __forceinline__ bool box_all_hit(float4 n0, float4 n1, V3 o, const Ti
     return leave - enter > margin && leave < 1.0e30f;   // NaN anywhere -> false
 }
 
-constexpr int kChainBatch = 8;   // boxes tested per round of loads in chain_ok
+#ifndef CRT_CHAIN_BATCH
+#define CRT_CHAIN_BATCH 8
+#endif
+constexpr int kChainBatch = CRT_CHAIN_BATCH;   // boxes tested per round of loads in chain_ok
 
 // The chain test for one lane's winner `slot`: levels [first_level, depth] of its path (the levels above are
 // proven for the whole tile).  Loads come in rounds: the path's node indices, then up to kChainBatch nodes at once.

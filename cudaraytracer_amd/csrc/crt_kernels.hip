@@ -2105,7 +2105,10 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     }
     if (d_bvh_tiles) {   // the tree as the world: staged light tiles + tree walks, no heavy phase (every tile is queued as light)
         group = 8;
-        fn = shade_tiles_kernel<true, 4, 8, true>;   // 128 VGPRs: the chain test holds a batch of boxes
+#ifndef CRT_BVH_OCC
+#define CRT_BVH_OCC 4   // 128 VGPRs: the chain test holds a batch of boxes
+#endif
+        fn = shade_tiles_kernel<true, CRT_BVH_OCC, 8, true>;
         heavy = -1;      // as unsigned: no tile is heavier
         if (bvh_force_general) dbg_repeat = -77;
     }
