@@ -361,7 +361,7 @@ __device__ __forceinline__ bool box_all_hit(float4 n0, float4 n1, V3 o, const Ti
 }
 
 #ifndef CRT_CHAIN_BATCH
-#define CRT_CHAIN_BATCH 8
+#define CRT_CHAIN_BATCH 4
 #endif
 constexpr int kChainBatch = CRT_CHAIN_BATCH;   // boxes tested per round of loads in chain_ok
 

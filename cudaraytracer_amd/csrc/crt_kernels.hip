@@ -2106,7 +2106,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (d_bvh_tiles) {   // the tree as the world: staged light tiles + tree walks, no heavy phase (every tile is queued as light)
         group = 8;
 #ifndef CRT_BVH_OCC
-#define CRT_BVH_OCC 4   // 128 VGPRs: the chain test holds a batch of boxes
+#define CRT_BVH_OCC 6   // measured (profiles/r2_tiled/sweep_bvh.txt): 6 waves/SIMD with batches of 4 boxes beat 4 waves/SIMD with 8
 #endif
         fn = shade_tiles_kernel<true, CRT_BVH_OCC, 8, true>;
         heavy = -1;      // as unsigned: no tile is heavier

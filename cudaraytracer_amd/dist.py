@@ -84,18 +84,13 @@ def gather_framebuffer(band, nx, ny, rank, world_size, group=None, bufs=None):
     return full.reshape(ny, nx, 3)
 
 
-def gather_strips(piece, nx, ny, rank, world_size, strip_rows=STRIP_ROWS, group=None, bufs=None):
-    """Round-robin strips: `piece` holds this rank's strips one after the other.  One gather;
-    rank 0 then puts all complete rounds of strips in place with ONE strided copy
-    (full[g, r] = parts[r, g] for round g, rank r) and the ragged last round strip by strip."""
-    if world_size == 1:
-        return piece.reshape(ny, nx, 3)
-    rows_of = [sum(c for _, c in partition_strips(ny, world_size, r, strip_rows)) for r in range(world_size)]
-    parts = _gather_padded(piece, max(rows_of) * nx * 3, rank, world_size, group, bufs)
-    if parts is None:
-        return None
+def assemble_parts(parts, nx, ny, world_size, strip_rows=STRIP_ROWS):
+    """Rank 0 after the gather: parts[r] holds rank r's strips one after the other (padded to the
+    longest piece).  On the device: the library's reassembly kernel (crt_assemble_strips) on the
+    current stream.  On the CPU (gloo rehearsals): all complete rounds of strips with ONE strided
+    copy (full[g, r] = parts[r, g] for round g, rank r) and the ragged last round strip by strip."""
     full = parts.new_empty(ny, nx, 3)
-    if parts.is_cuda:      # the root's reassembly kernel (crt_assemble_strips) on the current stream
+    if parts.is_cuda:
         from . import api
         api.assemble_strips(parts, parts.stride(0), nx, ny, strip_rows, world_size, full,
                             stream=torch.cuda.current_stream())
@@ -111,6 +106,19 @@ def gather_strips(piece, nx, ny, rank, world_size, strip_rows=STRIP_ROWS, group=
             full[y0:y0 + c] = parts[r][at * nx * 3:(at + c) * nx * 3].view(c, nx, 3)
             at += c
     return full
+
+
+def gather_strips(piece, nx, ny, rank, world_size, strip_rows=STRIP_ROWS, group=None, bufs=None):
+    """Round-robin strips: `piece` holds this rank's strips one after the other.  One gather of
+    padded pieces to rank 0 (torch.distributed.gather: RCCL under the "nccl" backend), then
+    assemble_parts there."""
+    if world_size == 1:
+        return piece.reshape(ny, nx, 3)
+    rows_of = [sum(c for _, c in partition_strips(ny, world_size, r, strip_rows)) for r in range(world_size)]
+    parts = _gather_padded(piece, max(rows_of) * nx * 3, rank, world_size, group, bufs)
+    if parts is None:
+        return None
+    return assemble_parts(parts, nx, ny, world_size, strip_rows)
 
 
 class BandRenderer:

@@ -82,6 +82,29 @@ def test_assemble_strips_kernel(gpu, crt_built, nx, ny, world):
     assert np.array_equal(bits(full.cpu().numpy().reshape(ny, nx, 3)), bits(want))
 
 
+def test_dist_assemble_parts_device_branch(gpu):
+    """cudaraytracer_amd.dist.assemble_parts on device tensors (what rank 0 runs after the RCCL gather in
+    bench.py --gpus N): the [W, max] receive buffer of padded pieces -> the frame, via crt_assemble_strips;
+    equal to the CPU branch on the same data."""
+    from cudaraytracer_amd import dist
+    sc = scenes.displaced_sphere(24, 30)
+    for nx, ny, world in [(642, 360, 8), (90, 150, 3)]:          # 642 * 3 is not a multiple of 4: the scalar kernel
+        spp = 2
+        scene, cam = make(sc, nx, ny)
+        want = full_frame(gpu, scene, cam, nx, ny, spp)
+        rows_of = [sum(c for _, c in dist.partition_strips(ny, world, r)) for r in range(world)]
+        parts = gpu.zeros((world, max(rows_of) * nx * 3), dtype=gpu.float32, device="cuda")
+        for r in range(world):
+            if rows_of[r] == 0:
+                continue
+            st = api.CurandState.for_strips(nx, ny, r, 32, world, 0)
+            api.render_strips(scene, cam, st, nx, ny, spp, r, 32, world, parts[r], stream=gpu.cuda.current_stream())
+        got = dist.assemble_parts(parts, nx, ny, world)
+        gpu.cuda.synchronize()
+        assert np.array_equal(bits(got.cpu().numpy()), bits(want))
+        assert np.array_equal(bits(dist.assemble_parts(parts.cpu(), nx, ny, world).numpy()), bits(want))
+
+
 def _rccl():
     """The RCCL copy this process holds (torch's), through ctypes: ncclCommInitAll over device 0."""
     lib = C.CDLL("librccl.so.1")
