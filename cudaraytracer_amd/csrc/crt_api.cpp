@@ -95,6 +95,16 @@ int ensure_workspace(Context& ws, int nx, int rows) {
         HIP_TRY(hipMalloc(&ws.w.counters, crt::kCtrWords * sizeof(uint32_t)));
         ws.w.counters64 = reinterpret_cast<unsigned long long*>(ws.w.counters);
     }
+    // the walk's log: one record per (wavefront, tile) pair with survivors — fewer than list entries; same bound
+    const size_t want_log = std::min<size_t>(std::max<size_t>((size_t)4 << 20, tiles * 64), (size_t)1 << 27);
+    if (want_log > ws.log_entries) {
+        if (ws.w.log) (void)hipFree(ws.w.log);
+        ws.w.log = nullptr;
+        ws.log_entries = 0;
+        HIP_TRY(hipMalloc(&ws.w.log, want_log * sizeof(crt::BinRecord)));
+        ws.log_entries = want_log;
+    }
+    ws.w.log_cap = (uint32_t)ws.log_entries;
     if (want_pool > ws.pool_entries) {
         if (ws.w.pool) (void)hipFree(ws.w.pool);
         ws.w.pool = nullptr;
@@ -781,6 +791,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     if (g_variant == 0 || g_variant == 2) kernel_variant = tiled_ok ? 1 : 0;
     else if (g_variant == 3) kernel_variant = tiled_ok ? 2 : 0;
     else if (g_variant == 4) kernel_variant = tiled_ok ? 3 : 0;   // tiled, scalar-operand walk for light tiles too (A/B)
+    else if (g_variant == 8) kernel_variant = tiled_ok ? 4 : 0;   // tiled with a 16-record binning log (overflow fallback)
 
     crt::RenderParams p;
     memcpy(p.cam.llc, camera->lower_left_corner, 12);

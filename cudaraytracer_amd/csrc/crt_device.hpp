@@ -84,7 +84,15 @@ hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const R
 // overflow fallbacks); 3: tiled with the scalar-operand walk also for light tiles (A/B of
 // the LDS-staged records).  d_cls may be null for variant 0.
 // Scratch of the tiled variant (device pointers; owned by the host layer, grow-only).
+// What one wavefront of the binning walk found in one tile: the survivors among its 64 triangles.
+struct BinRecord {
+    uint32_t tile, base;             // tile id; first triangle of the wavefront
+    unsigned long long mask, sure;   // lanes (triangles) that may be hit in the tile; those whose cull test cannot reject there
+};
+
 struct TiledWork {
+    BinRecord* log;                  // the walk's records (bin_tri_kernel -> bin_fill_kernel)
+    uint32_t log_cap;                // records
     uint32_t* pool;                  // survivor indices of all tiles, bump-allocated
     unsigned long long* counters64;  // [0] pool cursor (entries)
     uint32_t pool_cap;               // entries
@@ -104,6 +112,8 @@ constexpr int kCtrQueueLen = 2;      // counters[0..1] alias counters64[0]; [2 +
 // Consumer cursors of the shading kernel.  Returning atomics on one address serialise in L2
 // (~60 ns each, measured), so every hot cursor has its own 128-byte line and the light queue
 // is cut into kLightChunks chunks with one cursor each.
+constexpr int kCtrLogCursor = 24;                  // records appended to TiledWork::log
+constexpr int kCtrLogOverflow = 25;                // != 0: the log was full, every tile walks the whole list
 constexpr int kCtrLine = 32;                       // words per 128-byte line
 constexpr int kCtrHeavyCursor = 2 * kCtrLine;      // next item of the concatenated heavy classes
 constexpr int kLightChunks = 64;

@@ -38,7 +38,7 @@ struct Context {
     hipStream_t stream = nullptr;
     std::mutex mu;                   // host-side: two threads enqueueing on the same stream
     crt::TiledWork w{};
-    size_t pool_entries = 0, tiles = 0;
+    size_t pool_entries = 0, tiles = 0, log_entries = 0;
     int n_cus = 0;
     float* d_rec = nullptr;          // n x 16 derived records (tri_prepass output)
     float4* d_cls = nullptr;         // 5 planes x n_pad classification records (cls_prepass output)

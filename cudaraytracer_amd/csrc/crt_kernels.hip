@@ -803,13 +803,37 @@ __device__ __forceinline__ bool cell_may_hit(const float c[5], const float q[5])
     return cull_ok && (pos || neg);
 }
 
-// FILL 0: count the survivors of every tile.  FILL 1 (after bin_alloc_kernel): write them.
-// Control flow is wave-uniform (ballots), so every tile costs one atomic per wavefront that
-// touches it.
-template <int FILL>
+// ONE walk (round 2; round 1 walked twice, count then fill, and the fill pass waited on one returning atomic per
+// wavefront and tile): the walk counts the survivors of every tile (fire-and-forget atomics) and logs what it
+// found — records (tile, first triangle of the wavefront, 64-bit survivor mask, 64-bit cull-sure mask) collected
+// in LDS and appended to a global log kBinLogCap at a time.  After bin_alloc_kernel has placed the tiles' lists,
+// bin_fill_kernel turns every record into list entries, one record per lane: the returning atomics that order
+// the writers of a tile are then spread over thousands of lanes instead of serialised inside the busiest walk.
+// Control flow is wave-uniform (ballots).
+constexpr int kBinLogCap = 128;   // records buffered per wavefront (3 KB of LDS)
+
+__device__ __forceinline__ void bin_log_flush(BinRecord* slog, unsigned& n_log, const TiledWork& w, int lane) {
+    if (n_log == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&w.counters[kCtrLogCursor], n_log);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if ((unsigned long long)base + n_log > (unsigned long long)w.log_cap) {
+        if (lane == 0) w.counters[kCtrLogOverflow] = 1u;   // bin_alloc_kernel then gives every tile the whole list
+    } else {
+        for (unsigned k = (unsigned)lane; k < n_log; k += 64u) w.log[base + k] = slog[k];
+    }
+    n_log = 0u;
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ void __launch_bounds__(kBinThreads)
 bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledWork w,
                unsigned long long* __restrict__ stats, int few_triangles) {
+    __shared__ BinRecord slog[kBinLogCap];
+    unsigned n_log = 0u;   // wave-uniform
     unsigned n_region_hit = 0, n_tile_box = 0, n_tile_hit = 0;   // diagnostics (wave-uniform)
     const long long clk0 = stats ? (long long)clock64() : 0;
     const int tri = blockIdx.x * kBinThreads + threadIdx.x;
@@ -913,8 +937,6 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
                 const bool tile_ok = tx < w.tiles_x && ty < w.tiles_y;
                 const int tile = ty * w.tiles_x + tx;
                 const float uct = (float)(tx * 8 + 4) * rnx, vct = (float)(gy + lty * 8 + 4) * rny;
-                uint2 desc = make_uint2(0u, kNoList);
-                if (FILL != 0 && tile_ok) desc = w.tile_desc[tile];
                 for (unsigned long long mm = m1; mm != 0ull; mm &= mm - 1ull) {
                     const int src = (int)__builtin_ctzll(mm);
                     float q5[5];
@@ -927,15 +949,20 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
                     const float4 bx = sform[5][src];   // tu_lo, tu_hi, tv_lo, tv_hi
                     const bool s2 = tile_ok && !(vct < bx.z) && !(vct > bx.w) && !(uct < bx.x) && !(uct > bx.y) && cell_may_hit(c, q5);
                     n_tile_box += 64u;
-                    if (s2) {
-                        const unsigned tri_src = (unsigned)(blockIdx.x * kBinThreads + src);
-                        if (FILL == 0) {
-                            atomicAdd(&w.tile_count[tile], 1u);
-                        } else if (desc.y != kNoList) {
-                            const unsigned at = atomicSub(&w.tile_count[tile], 1u) - 1u;
-                            w.pool[(size_t)desc.x + at] = tri_src | ((c[0] > q5[0]) ? kCullSureBit : 0u);
-                        }
+                    const unsigned long long ms = __builtin_amdgcn_ballot_w64(s2);
+                    if (ms == 0ull) continue;
+                    const unsigned n_rec = (unsigned)__builtin_popcountll(ms);
+                    if (n_log + n_rec > (unsigned)kBinLogCap) bin_log_flush(slog, n_log, w, lane);
+                    if (s2) {   // one record per surviving tile: this triangle alone
+                        atomicAdd(&w.tile_count[tile], 1u);
+                        BinRecord r;
+                        r.tile = (uint32_t)tile;
+                        r.base = (uint32_t)(blockIdx.x * kBinThreads);
+                        r.mask = 1ull << src;
+                        r.sure = (c[0] > q5[0]) ? (1ull << src) : 0ull;
+                        slog[n_log + (unsigned)__builtin_popcountll(ms & lanemask_lt)] = r;
                     }
+                    n_log += n_rec;
                 }
                 continue;
             }
@@ -960,25 +987,26 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
                     ++n_tile_hit;
                     const int tile = ty * w.tiles_x + tx;
                     const unsigned n = (unsigned)__builtin_popcountll(m);
-                    if (FILL == 0) {
-                        if (lane == 0) atomicAdd(&w.tile_count[tile], n);
-                    } else {
-                        const uint2 desc = w.tile_desc[tile];
-                        if (desc.y == kNoList) continue;
-                        // the count doubles as the fill cursor: it is back at 0 after this pass
-                        unsigned at = 0;
-                        if (lane == 0) at = atomicSub(&w.tile_count[tile], n) - n;
-                        at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
-                        // cull-sure: c_dn - r_dn > S_dn with the same r, S  <=>  c_dn > q_dn
-                        if (s2)
-                            w.pool[(size_t)desc.x + at + (unsigned)__builtin_popcountll(m & lanemask_lt)] =
-                                (unsigned)tri | ((c[0] > qt[0]) ? kCullSureBit : 0u);
+                    // cull-sure: c_dn - r_dn > S_dn with the same r, S  <=>  c_dn > q_dn
+                    const unsigned long long msure = __builtin_amdgcn_ballot_w64(s2 && c[0] > qt[0]);
+                    if (n_log + 1u > (unsigned)kBinLogCap) bin_log_flush(slog, n_log, w, lane);
+                    if (lane == 0) {
+                        atomicAdd(&w.tile_count[tile], n);
+                        BinRecord r;
+                        r.tile = (uint32_t)tile;
+                        r.base = (uint32_t)(blockIdx.x * kBinThreads);
+                        r.mask = m;
+                        r.sure = msure;
+                        slog[n_log] = r;
                     }
+                    n_log += 1u;
                 }
             }
         }
     }
-    if (FILL == 0 && stats && lane == 0) {   // cells a wavefront walks, per level
+    __builtin_amdgcn_wave_barrier();
+    bin_log_flush(slog, n_log, w, lane);
+    if (stats && lane == 0) {   // cells a wavefront walks, per level
         atomicAdd(&stats[0], 1ull);
         atomicAdd(&stats[1], (unsigned long long)n_region_hit);
         atomicAdd(&stats[2], (unsigned long long)n_tile_box);
@@ -1021,7 +1049,7 @@ bin_alloc_kernel(TiledWork w, int heavy_min, unsigned shade_blocks, unsigned lon
     if (tid == 0) block_base = total ? atomicAdd(&w.counters64[0], (unsigned long long)total) : 0ull;
     __syncthreads();
     const unsigned long long base = block_base;
-    const bool fits = base + total <= (unsigned long long)w.pool_cap;   // per block of tiles
+    const bool fits = base + total <= (unsigned long long)w.pool_cap && w.counters[kCtrLogOverflow] == 0u;   // per block of tiles
     if (valid) {
         w.tile_desc[tile] = fits ? make_uint2((unsigned)base + before + (incl - cnt), cnt) : make_uint2(0u, kNoList);
         if (!fits) w.tile_count[tile] = 0u;                // no fill pass for this tile
@@ -1067,7 +1095,26 @@ bin_alloc_kernel(TiledWork w, int heavy_min, unsigned shade_blocks, unsigned lon
     }
 }
 
-// binning of one launch: count, allocate, fill (all on `stream`)
+// One log record per lane: its survivors become entries of the tile's list.  The count doubles as the fill cursor
+// (it is back at 0 afterwards); lists are unordered, the exact test breaks ties by index.
+__global__ void __launch_bounds__(256)
+bin_fill_kernel(TiledWork w) {
+    const unsigned n_rec = min(w.counters[kCtrLogCursor], w.log_cap);
+    if (w.counters[kCtrLogOverflow] != 0u) return;   // every tile walks the whole list (bin_alloc_kernel)
+    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {
+        const BinRecord rec = w.log[r];
+        const uint2 desc = w.tile_desc[rec.tile];
+        if (desc.y == kNoList) continue;
+        const unsigned n = (unsigned)__builtin_popcountll(rec.mask);
+        unsigned at = atomicSub(&w.tile_count[rec.tile], n) - n;
+        for (unsigned long long m = rec.mask; m != 0ull; m &= m - 1ull) {
+            const int j = (int)__builtin_ctzll(m);
+            w.pool[(size_t)desc.x + at++] = (rec.base + (unsigned)j) | (((rec.sure >> j) & 1ull) ? kCullSureBit : 0u);
+        }
+    }
+}
+
+// binning of one launch: walk (count + log), allocate, fill (all on `stream`)
 static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int n_pad, const TiledWork& w,
                                  int heavy_min, unsigned shade_blocks, unsigned long long* d_stats, bool prezeroed, hipStream_t stream) {
     hipError_t e = hipSuccess;
@@ -1087,10 +1134,10 @@ static hipError_t launch_binning(const RenderParams& p, const float4* d_cls, int
     const int slices_y = std::max(1, std::min(region_ny, waves_min / std::max(n_waves, 1)));
     const int slices_x = std::max(1, std::min(region_nx, waves_min / std::max(n_waves * slices_y, 1)));
     const dim3 grid_tri((unsigned)n_waves, (unsigned)slices_y, (unsigned)slices_x);
-    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<0>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats, few);
+    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats, few);
     hipLaunchKernelGGL(bin_alloc_kernel, dim3((unsigned)((w.tiles_total + kAllocThreads - 1) / kAllocThreads)), dim3(kAllocThreads), 0, stream, w,
                        heavy_min, shade_blocks, d_stats);
-    if (p.n_tris > 0) hipLaunchKernelGGL(bin_tri_kernel<1>, grid_tri, dim3(kBinThreads), 0, stream, p, d_cls, n_pad, w, d_stats, few);
+    if (p.n_tris > 0) hipLaunchKernelGGL(bin_fill_kernel, dim3(1024), dim3(256), 0, stream, w);
     return hipGetLastError();
 }
 
@@ -2072,6 +2119,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     }
     TiledWork w = *work;
     if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
+    if (variant == 4) w.log_cap = 16;                    // test hook: the binning log overflows, every tile walks the whole list
     // Blocks of 8 waves share a heavy tile (16-wave blocks have no LDS left for the balanced walk and
     // are slower at every launch size since it exists; kept for A/B through CRT_SHADE_GROUP).
     const int tiles_per_cu = w.tiles_total / std::max(n_cus, 1);
