@@ -1374,7 +1374,8 @@ __device__ __forceinline__ void trace_pairs(StageArea& area, const int* ent, con
 // chain_ok checks that winner's boxes — once per hit pixel, at full lane utilisation — and a
 // winner whose chain fails is excluded for that pixel and the walk repeated (rare).  Tiles with more
 // than 32 survivors (or without a list) and wave-samples off the hot direction chain take the
-// tree itself (bvh_trace).  There is no heavy phase: bin_alloc queues every tile as light.
+// tree itself (bvh_trace).  Heavy tiles keep the 8-wave scheme: the master wave publishes c3, merges the slices' keys and
+// checks the winner's chain.
 template <bool VREC, int OCC, int WAVES, bool BVH = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
@@ -1410,7 +1411,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     unsigned total_heavy = 0;
 #pragma unroll
     for (int c = 0; c < kHeavyClasses; ++c) total_heavy += w.counters[kCtrQueueLen + c];
-    if (!BVH) {
+    {
         unsigned item = blockIdx.x;
         while (item < total_heavy) {
             int c = 0;
@@ -1445,6 +1446,16 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
                                  global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
             }
+            // BVH mode: a slice must fit the staging area (the unstaged walks order ties by index, not by the tree's rule);
+            // tiles without a list or with more than 64 entries per wave walk the tree, wave 0 alone
+            const bool tree_tile = BVH && (walk_all || per > 64 || !VREC);
+            if (BVH && !tree_tile && n_lds > 0) {
+                if (lane < n_lds)   // the tree's tie order instead of the slot (see the light tiles)
+                    lent[wave][lane] = (int)(((unsigned)slice_mine & kCullSureBit) | (unsigned)(0x7fffffff - bvh->partner[slice_mine & 0x7fffffff]));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
             unsigned slice_pairs = 0xffffffffu;   // balanced walk of the staged part of the slice (rays and keys are in LDS anyway)
             if (VREC && WAVES <= 8 && n_lds > 0 && dbg_pairs != 0) {
                 if (!lane_valid) cand.lo = cand.hi = 0u;
@@ -1460,7 +1471,74 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
               }
             };
-            if (wave == 0) {
+            if (BVH && tree_tile) {
+                if (wave == 0) {
+                    BvhView view;
+                    view.nodes = bvh->nodes;
+                    view.n_nodes = bvh->n_nodes;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) view.rot[k] = bvh->rot[k];
+                    const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
+                    render_pixel<true, false, false>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                        V3 used;
+                        bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
+                    });
+                }
+            } else if (BVH && wave == 0) {
+                // Master wave, BVH mode: publishes c3 (what the triangles see on the hot chain), merges the slices' keys,
+                // checks the winner's chain of boxes; a lane off the hot chain or with an unreachable winner resolves its
+                // pixel alone from the tile's whole list (general_winner + chain_ok_general, excluding what fails).
+                const BvhTiles& bt = *bvh;
+                const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
+                const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, hly0));
+                const int first_level = __builtin_amdgcn_readfirstlane(
+                    tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[0], lane));
+                render_pixel<true, false, false>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                    const V3 c1 = rot0_exact(bt.rot, d1);
+                    const V3 c2 = chain_next<true>(bt.rot, c1);
+                    const V3 c3 = chain_next<true>(bt.rot, c2);
+                    const V3 c4 = chain_next<true>(bt.rot, c3);
+                    const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
+                                           fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
+                    const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f && dbg_repeat_in != -77;
+                    ray_d[0][lane] = c3.x;
+                    ray_d[1][lane] = c3.y;
+                    ray_d[2][lane] = c3.z;
+                    best_key[lane] = ~0ull;
+                    __syncthreads();   // B1
+                    int q = -1;
+                    float tb = FLT_MAX;
+                    trace_slice(c3, tb, q);
+                    if (q >= 0) atomicMin(&best_key[lane], hit_key(tb, q));
+                    __syncthreads();   // B2
+                    const unsigned long long kbest = best_key[lane];
+                    int slot = -1;
+                    bool alone = !hot;
+                    if (hot && kbest != ~0ull) {
+                        slot = bt.partner[0x7fffffff - (int)(unsigned)(kbest & 0xffffffffull)];
+                        alone = !chain_ok(bt, slot, first_level, lpath[0], o, c1, c2, c3);
+                    }
+                    if (alone) {   // per lane; masks: every entry of the list is a candidate
+                        const V3 c5 = rot0(bt.rot, unit_vector(c4));
+                        const int mode = hot ? 0 : (same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2));
+                        unsigned all[16], gex[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) { all[j] = 0xffffffffu; gex[j] = 0u; }
+                        for (;;) {
+                            const int qg = general_winner(bt, rec, lst, n_src, all, gex, 16, o, c1, c2, c3, c4, mode, slot);
+                            if (qg < 0 || chain_ok_general(bt, slot, o, c1, c2, c3, c4, mode)) break;
+                            for (int k = 0; k < n_src; ++k)
+                                if ((int)(lst[k] & 0x7fffffffu) == slot) {
+#pragma unroll
+                                    for (int j = 0; j < 16; ++j)
+                                        if ((k >> 5) == j) gex[j] |= 1u << (k & 31);
+                                }
+                        }
+                    }
+                    hit_idx = slot;
+                    closest = 0.0f;
+                });
+            } else if (wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
                 render_pixel<true>(p, x, ly, shade_n, state, rgb, lane_valid,
                              [&](V3, V3 d2, float& closest, int& hit_idx) {
@@ -1817,7 +1895,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     int slot = -1;
                     bool bad = false;
                     const int kw = q & 63;   // the winner's position in the staged list
+#ifdef CRT_DBG_NOCHAIN   // timing experiment only: the chain of boxes is not tested (wrong pixels where it matters)
+                    if (q >= 0 && hot) slot = lslot[wave][kw];
+                    if (false) {
+#else
                     if (q >= 0 && hot) {
+#endif
                         slot = lslot[wave][kw];
                         const int info = linfo[wave][kw];
                         if (info >> 16) {   // more levels than one batch: the general routine (global loads)
@@ -2151,13 +2234,12 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         fn = vrec ? (occ == 4 ? shade_tiles_kernel<true, 4, 16> : shade_tiles_kernel<true, 8, 16>)
                   : (occ == 4 ? shade_tiles_kernel<false, 4, 16> : shade_tiles_kernel<false, 8, 16>);
     }
-    if (d_bvh_tiles) {   // the tree as the world: staged light tiles + tree walks, no heavy phase (every tile is queued as light)
+    if (d_bvh_tiles) {   // the tree as the world (shade_tiles_kernel<.., BVH = true>)
         group = 8;
 #ifndef CRT_BVH_OCC
 #define CRT_BVH_OCC 6   // measured (profiles/r2_tiled/sweep_bvh.txt): 6 waves/SIMD with batches of 4 boxes beat 4 waves/SIMD with 8
 #endif
         fn = shade_tiles_kernel<true, CRT_BVH_OCC, 8, true>;
-        heavy = -1;      // as unsigned: no tile is heavier
         if (bvh_force_general) dbg_repeat = -77;
     }
     // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b);
