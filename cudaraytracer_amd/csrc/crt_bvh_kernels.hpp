@@ -454,6 +454,31 @@ __device__ __forceinline__ int general_winner(const BvhTiles& bt, const float* _
     return best_q;
 }
 
+// The same over the WHOLE list of a tile (no candidate masks), minus up to 8 excluded slots: heavy tiles, whose masks
+// live in other wavefronts.
+__device__ __forceinline__ int general_winner_all(const BvhTiles& bt, const float* __restrict__ rec, const uint32_t* __restrict__ lst, int cnt,
+                                                  const int* excl, int n_excl, V3 o, V3 c1, V3 c2, V3 c3, V3 c4, int mode, int& slot_out) {
+    float best_t = FLT_MAX;
+    int best_q = -1, best_slot = -1;
+    for (int k = 0; k < cnt; ++k) {
+        const int slot = (int)(lst[k] & 0x7fffffffu);
+        bool skip = false;
+        for (int j = 0; j < n_excl; ++j) skip = skip || excl[j] == slot;
+        if (skip) continue;
+        const int depth = (bt.slot_leaf[slot] >> 24) & 31;
+        float t;
+        if (!tri_hit_lane<true, true>(rec, slot, o, chain_at<true>(bt.rot, depth + 3, c1, c2, c3, c4, mode), t)) continue;
+        const int q = 0x7fffffff - bt.partner[slot];
+        if (t < best_t || (t == best_t && q < best_q)) {
+            best_t = t;
+            best_q = q;
+            best_slot = slot;
+        }
+    }
+    slot_out = best_slot;
+    return best_q;
+}
+
 // Per tile, wave-uniform: the reference path = the path of `slot0` (copied to tile_path, LDS), and the first of its
 // levels whose box is not proven hit for every ray of the tile.
 __device__ __forceinline__ int tile_reference_path(const BvhTiles& bt, int slot0, V3 o, const TileCone& cone, int* __restrict__ tile_path, int lane) {

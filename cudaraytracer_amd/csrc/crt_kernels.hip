@@ -1438,7 +1438,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             // sample and shades; the other waves only trace.  Two barriers per sample:
             // B1 "rays are in LDS", B2 "partial minima are in LDS".
             // this wave's slice: the first 64 entries are staged in LDS like a light tile's list
-            const int n_lds = (VREC && !walk_all) ? min(64, k1 - k0) : 0;
+            // BVH mode: a slice of up to 64 entries is staged once like below; up to 256 entries pass through the staging
+            // area in chunks of 64 per sample (candidate masks kept per chunk); tiles without a list or with longer slices
+            // walk the tree, wave 0 alone.  (The unstaged walks of the list world order ties by index, not by the tree's rule.)
+            const int s_chunks = (BVH && !walk_all) ? (k1 - k0 + 63) / 64 : 1;
+            const bool tree_tile = BVH && (walk_all || s_chunks > 4 || !VREC);
+            const bool multi = BVH && !tree_tile && s_chunks > 1;
+            const int n_lds = (VREC && !walk_all && !multi && !tree_tile) ? min(64, k1 - k0) : 0;
             int slice_mine = 0;
             Cand cand = {0u, 0u, 0u, 0u};
             if (n_lds > 0) {   // per-pixel candidates among the staged entries of this wave's slice
@@ -1446,9 +1452,23 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
                                  global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
             }
-            // BVH mode: a slice must fit the staging area (the unstaged walks order ties by index, not by the tree's rule);
-            // tiles without a list or with more than 64 entries per wave walk the tree, wave 0 alone
-            const bool tree_tile = BVH && (walk_all || per > 64 || !VREC);
+            Cand cc[4];
+            int e_c[4], q_c[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { cc[c] = Cand{0u, 0u, 0u, 0u}; e_c[c] = 0; q_c[c] = 0; }
+            if (multi) {
+                const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < s_chunks) {
+                        const int n = min(64, k1 - k0 - 64 * c);
+                        e_c[c] = (lane < n) ? (int)lst[k0 + 64 * c + lane] : 0;
+                        stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, e_c[c], n, lane, x, gy, cc[c]);
+                        if (!lane_valid) cc[c].lo = cc[c].hi = 0u;
+                        q_c[c] = (lane < n) ? (int)(((unsigned)e_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bvh->partner[e_c[c] & 0x7fffffff])) : 0;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+            }
             if (BVH && !tree_tile && n_lds > 0) {
                 if (lane < n_lds)   // the tree's tie order instead of the slot (see the light tiles)
                     lent[wave][lane] = (int)(((unsigned)slice_mine & kCullSureBit) | (unsigned)(0x7fffffff - bvh->partner[slice_mine & 0x7fffffff]));
@@ -1462,6 +1482,23 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 slice_pairs = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
             }
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
+              if (multi) {   // BVH mode, long slice: every chunk's exact records pass through the staging area again
+#pragma unroll
+                  for (int c = 0; c < 4; ++c) {
+                      if (c >= s_chunks) continue;
+                      __builtin_amdgcn_wave_barrier();
+                      if (lane < min(64, k1 - k0 - 64 * c)) {
+                          const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(e_c[c] & 0x7fffffff) * kRecFloats);
+                          lrec[wave][0][lane] = r[0]; lrec[wave][1][lane] = r[1]; lrec[wave][2][lane] = r[2]; lrec[wave][3][lane] = r[3];
+                          lent[wave][lane] = q_c[c];
+                      }
+                      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                      __builtin_amdgcn_wave_barrier();
+                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                      trace_candidates(lrec[wave], lent[wave], cc[c], d2, closest, hit_idx);
+                  }
+                  return;
+              }
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (slice_pairs != 0xffffffffu)
                     trace_pairs(lrec[wave], lent[wave], lpairs[wave], slice_pairs, lane,
@@ -1518,21 +1555,29 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         slot = bt.partner[0x7fffffff - (int)(unsigned)(kbest & 0xffffffffull)];
                         alone = !chain_ok(bt, slot, first_level, lpath[0], o, c1, c2, c3);
                     }
-                    if (alone) {   // per lane; masks: every entry of the list is a candidate
+                    if (alone) {   // per lane, over the tile's whole list
                         const V3 c5 = rot0(bt.rot, unit_vector(c4));
                         const int mode = hot ? 0 : (same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2));
-                        unsigned all[16], gex[16];
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) { all[j] = 0xffffffffu; gex[j] = 0u; }
+                        int gex[8];
+                        int n_ex = 0;
                         for (;;) {
-                            const int qg = general_winner(bt, rec, lst, n_src, all, gex, 16, o, c1, c2, c3, c4, mode, slot);
+                            const int qg = general_winner_all(bt, rec, lst, n_src, gex, n_ex, o, c1, c2, c3, c4, mode, slot);
                             if (qg < 0 || chain_ok_general(bt, slot, o, c1, c2, c3, c4, mode)) break;
-                            for (int k = 0; k < n_src; ++k)
-                                if ((int)(lst[k] & 0x7fffffffu) == slot) {
+                            if (n_ex == 8) {   // more unreachable winners than this lane keeps track of: the tree itself decides
+                                BvhView view;
+                                view.nodes = bt.nodes;
+                                view.n_nodes = bt.n_nodes;
 #pragma unroll
-                                    for (int j = 0; j < 16; ++j)
-                                        if ((k >> 5) == j) gex[j] |= 1u << (k & 31);
-                                }
+                                for (int k = 0; k < 9; ++k) view.rot[k] = bt.rot[k];
+                                V3 used;
+                                float tw;
+                                bvh_trace<true>(view, rec, o, d1, 0, tw, slot, used);
+                                break;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (j == n_ex) gex[j] = slot;
+                            ++n_ex;
                         }
                     }
                     hit_idx = slot;
