@@ -21,7 +21,7 @@ shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
 avg = {}
 for r in csv.DictReader(open(stats[0])):
     avg[r["Name"]] = float(r["AverageNs"]) * 1e-9
-for key, name in (("shade_tiles_kernel", "shade"), ("bin_tri_kernel<1>", "bin_fill")):
+for key, name in (("shade_tiles_kernel", "shade"), ("bin_tri_kernel", "bin_walk"), ("cls_prepass_kernel", "prepass")):
     match = [k for k in avg if key in k]
     if match:
         subprocess.call([sys.executable, os.path.join(root, "tools", "summarise_pmc.py"), prof, key, repr(avg[match[0]]),
