@@ -275,7 +275,7 @@ def main():
         # names the commit it was taken at).  The kernel time they are divided by IS this run's.
         traffic, traffic_src, valu = None, None, None
         for prof in ("r2_tiled", "r1_tiled"):
-            pmc = os.path.join(ROOT, "profiles", prof, "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin_fill"))
+            pmc = os.path.join(ROOT, "profiles", prof, "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin_walk"))
             if os.path.exists(pmc):
                 break
         if tiled and world == 1 and args.spp == SPP and os.path.exists(pmc):

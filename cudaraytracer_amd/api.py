@@ -334,10 +334,21 @@ def last_kernel_times():
 
 
 def tiled_stats(enable):
-    """crt_debug_tiled_stats: returns the 32 counters collected so far, then (re)starts or stops."""
+    """crt_debug_tiled_stats: returns the 48 counters collected so far, then (re)starts (1: full counters,
+    2: timeline only) or stops (0)."""
     out = (C.c_uint64 * 48)()
-    check(_lib.lib().crt_debug_tiled_stats(1 if enable else 0, out))
+    check(_lib.lib().crt_debug_tiled_stats(int(enable), out))
     return list(out)
+
+
+def wave_timeline(max_waves=8192):
+    """crt_debug_wave_timeline: (n, 3) array of 100 MHz time stamps (start, end of the shared-tile phase, end) per wavefront."""
+    import numpy as np
+    out = (C.c_uint64 * (3 * max_waves))()
+    n = _lib.lib().crt_debug_wave_timeline(out, max_waves)
+    if n < 0:
+        check(n)
+    return np.ctypeslib.as_array(out)[: 3 * n].reshape(n, 3).copy()
 
 
 def audit_tiles(scene, camera, nx, ny, samples, seed=0):

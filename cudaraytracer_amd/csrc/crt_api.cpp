@@ -929,26 +929,39 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     return CRT_OK;
 }
 
-int crt_debug_tiled_stats(int enable, uint64_t* out24) {   // out: kStatsWords = 48 words
-    // Diagnostics: per-thread device counters filled by the tiled kernel (regions, sum/max of the
-    // region survivor count, region overflows, tiles, sum/max of the tile survivor count, tile
-    // overflows, then a log2 histogram of the tile survivor count).  enable=1 allocates/zeroes,
-    // enable=0 frees; out24 (nullable) receives the current values first.
-    if (out24) {
-        memset(out24, 0, crt::kStatsWords * sizeof(uint64_t));
+int crt_debug_tiled_stats(int enable, uint64_t* out48) {   // out: kStatsWords = 48 words
+    // Diagnostics: per-thread device counters filled by the tiled kernels (include/crt.h).  enable=1 allocates/zeroes,
+    // enable=2 the same in timeline mode, enable=0 frees; out48 (nullable) receives the current values first.
+    if (out48) {
+        memset(out48, 0, crt::kStatsWords * sizeof(uint64_t));
         if (g_d_stats) {
             HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipMemcpy(out24, g_d_stats, crt::kStatsWords * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(out48, g_d_stats, crt::kStatsWords * sizeof(uint64_t), hipMemcpyDeviceToHost));
         }
     }
     if (enable) {
-        if (!g_d_stats) HIP_TRY(hipMalloc(&g_d_stats, crt::kStatsWords * sizeof(uint64_t)));
-        HIP_TRY(hipMemset(g_d_stats, 0, crt::kStatsWords * sizeof(uint64_t)));
+        if (!g_d_stats) HIP_TRY(hipMalloc(&g_d_stats, crt::kStatsTotalWords * sizeof(uint64_t)));
+        HIP_TRY(hipMemset(g_d_stats, 0, crt::kStatsTotalWords * sizeof(uint64_t)));
+        if (enable == 2) {   // timeline mode: only wave time stamps, the kernel's timing stays what it is
+            const uint64_t one = 1ull;
+            HIP_TRY(hipMemcpy(g_d_stats + crt::kStatsTimeline, &one, sizeof(one), hipMemcpyHostToDevice));
+        }
     } else if (g_d_stats) {
         (void)hipFree(g_d_stats);
         g_d_stats = nullptr;
     }
     return CRT_OK;
+}
+
+int crt_debug_wave_timeline(uint64_t* out, int max_waves) {
+    // Timeline mode of crt_debug_tiled_stats: three 100 MHz time stamps (start, end of the shared-tile phase, end) per
+    // wavefront of the last shade_tiles_kernel launch, 3 * max_waves words; returns the number of slots copied.
+    if (!out || max_waves <= 0) return fail(CRT_ERR_INVALID, "crt_debug_wave_timeline: bad arguments");
+    if (!g_d_stats) return fail(CRT_ERR_INVALID, "crt_debug_wave_timeline: stats are not enabled");
+    const int n = std::min(max_waves, crt::kStatsWaveSlots);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, g_d_stats + crt::kStatsWaveLog, (size_t)n * 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return n;
 }
 
 int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t* mismatches);

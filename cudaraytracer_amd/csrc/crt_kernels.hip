@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace crt {
 
@@ -542,6 +543,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
         }
     }
 
+    const bool wave_has_pixel0 = __builtin_amdgcn_ballot_w64(pixel_index == 0) != 0ull;
     for (int smp = 0; smp < p.samples; ++smp) {
         float u, v;
         if (FASTDIV) {   // same bits as the IEEE divides (see div_by_rcp; numerators >= 2^-33, divisors 1..2^24)
@@ -554,7 +556,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
         // get_ray(u, v, state): the lens sample comes from state[0] (render.h:118,
         // camera.h:6-13,41).  With lens_radius == 0 only its side effect on stream 0
         // exists; under serial-order semantics only pixel 0 observes it.
-        if (pixel_index == 0) {
+        if (wave_has_pixel0 && pixel_index == 0) {                      // (wave-uniform test first: one scalar branch for every other tile)
             float px, py;
             do {
                 px = 2.0f * xw_uniform(rs) - 1.0f;
@@ -638,8 +640,9 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 // guard of the fast quotient is decided once per tile when the tile's d0.y cannot come near zero:
 // d0.y is affine in (u, v), so its range over the tile follows from the four corners, and
 // |d0| <= 2^40 holds for every bounded camera.
-__device__ __forceinline__ void render_sky_pixel(const RenderParams& p, int x, int ly, uint32_t* __restrict__ state,
-                                                 float* __restrict__ rgb) {
+template <bool HAS_PIXEL0>   // does the wavefront hold pixel 0 of the frame (the only one that draws lens samples)?
+__device__ __forceinline__ void render_sky_pixel_impl(const RenderParams& p, int x, int ly, uint32_t* __restrict__ state,
+                                                      float* __restrict__ rgb) {
     const int y = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
     const long long pixel_index = (long long)y * p.nx + x;
     const long long si = (long long)ly * p.nx + x, stride = p.rng_count;
@@ -677,10 +680,10 @@ __device__ __forceinline__ void render_sky_pixel(const RenderParams& p, int x, i
         guard_needed = __builtin_amdgcn_ballot_w64(!safe) != 0ull;
     }
     float colx = 0.0f, coly = 0.0f, colz = 0.0f;
-    for (int smp = 0; smp < p.samples; ++smp) {
+    auto one_sample = [&](auto guarded) {   // guarded: std::true_type = keep the per-sample range vote of unit_vector_fast_y
         const float u = div_by_rcp(fx + xw_uniform(rs), fnx, rnx);     // render.h:116
         const float v = div_by_rcp(fy + xw_uniform(rs), fny, rny);     // render.h:117
-        if (pixel_index == 0) {                                        // lens sample from state[0] (render.h:118): DESIGN.md §1
+        if (HAS_PIXEL0 && pixel_index == 0) {                          // lens sample from state[0] (render.h:118): DESIGN.md §1
             float px, py;
             do {
                 px = 2.0f * xw_uniform(rs) - 1.0f;
@@ -690,18 +693,32 @@ __device__ __forceinline__ void render_sky_pixel(const RenderParams& p, int x, i
         const float dx = ((llx + u * hx) + v * vx) - ox;               // camera.h:43
         const float dy = ((lly + u * hy) + v * vy) - oy;
         const float dz = ((llz + u * hz) + v * vz) - oz;
-        float uy;
-        if (guard_needed) {
-            uy = unit_vector_fast_y(V3{dx, dy, dz});
+        if (decltype(guarded)::value) {
+            const float uy = unit_vector_fast_y(V3{dx, dy, dz});
+            const float t = 0.5f * (uy + 1.0f);                        // backgroundSky, render.h:41-46
+            colx += 1.0f + t * (0.5f - 1.0f);
+            coly += 1.0f + t * (0.7f - 1.0f);
+            colz += 1.0f + t * (1.0f - 1.0f);
         } else {   // unit_vector_fast_y without its per-sample range vote
             const float s2 = dx * dx + dy * dy + dz * dz;
             const float len = sqrt_normal(s2);
-            uy = div_by_rcp(dy, len, reciprocal<true>(len));
+            const float uy = div_by_rcp(dy, len, reciprocal<true>(len));
+            const float t = 0.5f * (uy + 1.0f);
+            colx += 1.0f + t * (0.5f - 1.0f);
+            coly += 1.0f + t * (0.7f - 1.0f);
+            colz += 1.0f;                                              // t is finite here: 1 + t * (1 - 1) is 1 exactly
         }
-        const float t = 0.5f * (uy + 1.0f);                            // backgroundSky, render.h:41-46
-        colx += 1.0f + t * (0.5f - 1.0f);
-        coly += 1.0f + t * (0.7f - 1.0f);
-        colz += 1.0f + t * (1.0f - 1.0f);
+    };
+    // Five samples = ten draws bring the five XORWOW words back to the registers they started in: in blocks of five
+    // the state rotation needs no copies (a tile holding pixel 0 draws a varying number and keeps the plain loop).
+    if (guard_needed) {
+        for (int smp = 0; smp < p.samples; ++smp) one_sample(std::true_type{});
+    } else {
+        const std::false_type g{};
+        int smp = 0;
+        if (!HAS_PIXEL0)
+            for (; smp + 5 <= p.samples; smp += 5) { one_sample(g); one_sample(g); one_sample(g); one_sample(g); one_sample(g); }
+        for (; smp < p.samples; ++smp) one_sample(g);
     }
     const float k = (float)(1.0 / (double)(float)p.samples);           // vec3.h:182-189
     colx *= k; coly *= k; colz *= k;
@@ -713,6 +730,14 @@ __device__ __forceinline__ void render_sky_pixel(const RenderParams& p, int x, i
     rgb[o + 0] = colx; rgb[o + 1] = coly; rgb[o + 2] = colz;
     state[0 * stride + si] = rs.d; state[1 * stride + si] = rs.v0; state[2 * stride + si] = rs.v1;
     state[3 * stride + si] = rs.v2; state[4 * stride + si] = rs.v3; state[5 * stride + si] = rs.v4;
+}
+
+__device__ __forceinline__ void render_sky_pixel(const RenderParams& p, int x, int ly, uint32_t* __restrict__ state,
+                                                 float* __restrict__ rgb) {
+    const bool wave_has_pixel0 =
+        __builtin_amdgcn_ballot_w64(x == 0 && global_row(p.row_begin, p.strip_rows, p.strip_step, ly) == 0) != 0ull;
+    if (wave_has_pixel0) render_sky_pixel_impl<true>(p, x, ly, state, rgb);
+    else render_sky_pixel_impl<false>(p, x, ly, state, rgb);
 }
 
 // ---------------------------------------------------------------- variant 0: brute force
@@ -1380,7 +1405,12 @@ template <bool VREC, int OCC, int WAVES, bool BVH = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
-                   TiledWork w, unsigned long long* __restrict__ stats, int dbg_repeat_in, const BvhTiles* __restrict__ bvh) {
+                   TiledWork w, unsigned long long* __restrict__ stats_in, int dbg_repeat_in, const BvhTiles* __restrict__ bvh) {
+    // diagnostics: stats_in[kStatsTimeline] != 0 selects the light-weight timeline (wave start/end times only), which
+    // leaves the kernel's timing intact; otherwise the full counters (which roughly double the kernel time)
+    const bool timeline = stats_in != nullptr && stats_in[kStatsTimeline] != 0ull;
+    unsigned long long* __restrict__ stats = timeline ? nullptr : stats_in;
+    const unsigned long long wall0 = timeline ? (unsigned long long)wall_clock64() : 0ull;
     __shared__ unsigned long long best_key[64];   // per pixel: min over the waves of (ordered t, index)
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
@@ -1411,6 +1441,19 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     unsigned total_heavy = 0;
 #pragma unroll
     for (int c = 0; c < kHeavyClasses; ++c) total_heavy += w.counters[kCtrQueueLen + c];
+#ifndef CRT_PRIO
+#define CRT_PRIO 1
+#endif
+#ifndef CRT_PRIO_HEAVY
+#define CRT_PRIO_HEAVY 3
+#define CRT_PRIO_GEOM 1
+#define CRT_PRIO_SKY 0
+#endif
+#if CRT_PRIO
+    // Issue priority by item length: the shared (heavy) tiles are the longest serial chains of the launch and decide
+    // when it ends; light tiles with geometry come next; sky tiles are the filler.
+    __builtin_amdgcn_s_setprio(CRT_PRIO_HEAVY);
+#endif
     {
         unsigned item = blockIdx.x;
         while (item < total_heavy) {
@@ -1633,6 +1676,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         }
     }
     const long long clk1 = stats ? (long long)clock64() : 0;
+    const unsigned long long wall1 = timeline ? (unsigned long long)wall_clock64() : 0ull;
 
     // ---- light tiles: one wave per tile, lane = pixel
     // The light classes form one list, most survivors first; chunk k of kLightChunks owns the
@@ -1681,6 +1725,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         const int tile_id = __builtin_amdgcn_readfirstlane((int)w.queue[(size_t)(kHeavyClasses + lc) * w.tiles_total + item]);
         const uint2 desc = w.tile_desc[tile_id];
         const int cnt = __builtin_amdgcn_readfirstlane((int)desc.y);
+#if CRT_PRIO
+        if (cnt != 0) __builtin_amdgcn_s_setprio(CRT_PRIO_GEOM); else __builtin_amdgcn_s_setprio(CRT_PRIO_SKY);
+#endif
         const uint32_t* __restrict__ lst = w.pool + __builtin_amdgcn_readfirstlane(desc.x);
         const int x0 = (tile_id % w.tiles_x) * 8, ly0 = (tile_id / w.tiles_x) * 8;
         const int x = x0 + (lane & 7), ly = ly0 + (lane >> 3);
@@ -2064,6 +2111,15 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         atomicAdd(&stats[26], (unsigned long long)(clk2 - clk1));
         atomicMax(&stats[27], (unsigned long long)(clk2 - clk1));
         atomicMax(&stats[28], (unsigned long long)(clk2 - clk0));
+    }
+    if (timeline && lane == 0) {   // 100 MHz device-wide clock: when did this wave start, leave the heavy phase, end
+        const unsigned long long wall2 = (unsigned long long)wall_clock64();   // plain stores to the wave's own slot: same-address
+        const unsigned gw = blockIdx.x * WAVES + (unsigned)wave;              // atomics from 6 000 waves would cost more than the kernel
+        if (gw < (unsigned)kStatsWaveSlots) {
+            stats_in[kStatsWaveLog + 3 * gw + 0] = wall0;
+            stats_in[kStatsWaveLog + 3 * gw + 1] = wall1;
+            stats_in[kStatsWaveLog + 3 * gw + 2] = wall2;
+        }
     }
 }
 

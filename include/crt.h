@@ -282,9 +282,14 @@ int crt_set_kernel_variant(int variant);
  *   second barrier (cycles summed over [35] tiles with [36] survivors in total);
  *   per-pixel candidate masks of the light tiles with geometry: [37] tiles, [38] their list
  *   entries, [39] sum of the longest per-pixel candidate list of each, [40] sum of all lists.
- * Then enable != 0 (re)starts counting, enable == 0 stops it.  Counting costs a few atomics
- * and clock reads per wavefront. */
+ * Then enable != 0 (re)starts counting, enable == 0 stops it.  Counting costs atomics and clock
+ * reads that slow the kernels down (binning 7x, shading 1.4x); enable == 2 selects the TIMELINE
+ * mode instead: the shading kernel runs at full speed and every wavefront stores three time
+ * stamps of the device-wide 100 MHz clock (start, end of the shared-tile phase, end), read with
+ * crt_debug_wave_timeline (3 words per wavefront, index = block * waves per block + wave; returns
+ * the number of wavefront slots copied, at most max_waves). */
 int crt_debug_tiled_stats(int enable, uint64_t *out48);
+int crt_debug_wave_timeline(uint64_t *out, int max_waves);
 
 /* Audit of the tiled variant's binning (full nx x ny image on the current device): a brute-
  * force kernel tests every triangle against `samples` rays of every pixel (pixel-corner jitter

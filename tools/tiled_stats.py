@@ -32,3 +32,20 @@ print("bin busiest wavefront: regions %d, tiles box-tested %d, cycles %d" % tupl
 print("heavy tiles %d (sum survivors %d): master wave cycles per tile: setup+merge+shade %.0f, own trace %.0f, wait B2 %.0f" % (o[35], o[36], o[32]/max(o[35],1), o[33]/max(o[35],1), o[34]/max(o[35],1)))
 print("kernel ms", api.last_kernel_times())
 print("light tiles with geometry %d: list entries %.1f per tile; per-pixel candidates: longest of the wavefront %.1f, mean %.2f" % (o[37], o[38] / max(o[37], 1), o[39] / max(o[37], 1), o[40] / max(o[37], 1) / 64.0))
+
+# timeline mode: wave start / end times on the 100 MHz device clock, with the kernel's timing intact
+L.crt_debug_tiled_stats(2, None)
+for _ in range(40):   # warm clocks
+    api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d)
+torch.cuda.synchronize()
+tl = api.wave_timeline()
+tl = tl[tl[:, 2] > 0].astype(np.int64)
+t0 = tl[:, 0].min()
+start, mid, end = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0
+print("kernel ms", api.last_kernel_times())
+print("timeline of %d waves (us from the first start): last start %.1f, heavy phase ends: median %.1f p90 %.1f max %.1f, wave ends: p10 %.1f median %.1f p90 %.1f max %.1f, mean lifetime %.1f"
+      % (len(tl), start.max(), np.median(mid), np.percentile(mid, 90), mid.max(), np.percentile(end, 10), np.median(end), np.percentile(end, 90), end.max(), (end - start).mean()))
+edges = np.arange(0, end.max() + 25.0, 25.0)
+print("wave ends per 25 us:", np.histogram(end, edges)[0].tolist())
+print("heavy phase ends per 25 us (waves):", np.histogram(mid, edges)[0].tolist())
+L.crt_debug_tiled_stats(0, None)
