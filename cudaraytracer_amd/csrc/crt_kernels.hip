@@ -56,6 +56,15 @@ __device__ __forceinline__ float xw_uniform(Xorwow& s) {
     return (float)x * k + (k / 2.0f);
 }
 
+// 2.0f * curand_uniform(state) - 1.0f (material.h:14, camera.h:9): doubling is exact and commutes with the rounding of
+// the sum (no underflow: the terms are >= 2^-33), so 2u = x * 2^-31 + 2^-32 with the same single rounding — one
+// instruction less per draw in the rejection loops.
+__device__ __forceinline__ float xw_uniform_2m1(Xorwow& s) {
+    uint32_t x = xw_next(s);
+    const float k = 4.6566129e-10f;   // 2^-31
+    return ((float)x * k + (k / 2.0f)) - 1.0f;
+}
+
 // random_init (core/deviceManage.h:120-128): curand_init(seed, pixel_index, 0).
 // The 2^67-step subsequence skip is a product of precomputed GF(2) matrices
 // J_k = T^(2^(67+k)), one per set bit of pixel_index.  Matrix rows are wave-uniform
@@ -559,8 +568,8 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
         if (wave_has_pixel0 && pixel_index == 0) {                      // (wave-uniform test first: one scalar branch for every other tile)
             float px, py;
             do {
-                px = 2.0f * xw_uniform(rs) - 1.0f;
-                py = 2.0f * xw_uniform(rs) - 1.0f;
+                px = xw_uniform_2m1(rs);
+                py = xw_uniform_2m1(rs);
             } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);          // dot(p,p) with p.z = 2*0-0
         }
         // direction = lower_left_corner + s*horizontal + t*vertical - origin - offset, offset = 0
@@ -590,9 +599,9 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
             const float snx = sn[0], sny = sn[1], snz = sn[2];         // requested before the draws: the latency overlaps them
             float sxr, syr, szr;
             do {
-                sxr = 2.0f * xw_uniform(rs) - 1.0f;
-                syr = 2.0f * xw_uniform(rs) - 1.0f;
-                szr = 2.0f * xw_uniform(rs) - 1.0f;
+                sxr = xw_uniform_2m1(rs);
+                syr = xw_uniform_2m1(rs);
+                szr = xw_uniform_2m1(rs);
             } while (sxr * sxr + syr * syr + szr * szr >= 1.0f);
             float t = d0.x * snx + d0.y * sny + d0.z * snz;            // dot(r.direction(), rec.normal)
             if (t < 0.0f) t = 0.0f;
@@ -686,8 +695,8 @@ __device__ __forceinline__ void render_sky_pixel_impl(const RenderParams& p, int
         if (HAS_PIXEL0 && pixel_index == 0) {                          // lens sample from state[0] (render.h:118): DESIGN.md §1
             float px, py;
             do {
-                px = 2.0f * xw_uniform(rs) - 1.0f;
-                py = 2.0f * xw_uniform(rs) - 1.0f;
+                px = xw_uniform_2m1(rs);
+                py = xw_uniform_2m1(rs);
             } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);
         }
         const float dx = ((llx + u * hx) + v * vx) - ox;               // camera.h:43
@@ -2325,7 +2334,10 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int,
                              const BvhTiles*);
     ShadeFn fn;
-    if (group == 8) {
+    if (group == 4) {   // experiment (CRT_SHADE_GROUP=4): half as many waves parked per shared tile, more blocks free for light tiles at once
+        occ = 6;
+        fn = shade_tiles_kernel<true, 6, 4>;
+    } else if (group == 8) {
         occ = (occ == 4) ? 4 : 6;   // 8 waves per SIMD do not fit the LDS of the staged variant
         fn = vrec ? (occ == 6 ? shade_tiles_kernel<true, 6, 8> : shade_tiles_kernel<true, 4, 8>)
                   : (occ == 6 ? shade_tiles_kernel<false, 6, 8> : shade_tiles_kernel<false, 4, 8>);

@@ -83,9 +83,9 @@ __device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ V3 random_in_unit_sphere_dev(Xorwow& rs) {   // material.h:11-19, draws in x, y, z order
     V3 p;
     do {
-        p.x = 2.0f * xw_uniform(rs) - 1.0f;
-        p.y = 2.0f * xw_uniform(rs) - 1.0f;
-        p.z = 2.0f * xw_uniform(rs) - 1.0f;
+        p.x = xw_uniform_2m1(rs);
+        p.y = xw_uniform_2m1(rs);
+        p.z = xw_uniform_2m1(rs);
     } while (p.x * p.x + p.y * p.y + p.z * p.z >= 1.0f);
     return p;
 }
@@ -192,8 +192,8 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
         if (pixel_index == 0) {                                         // get_ray's lens sample from state[0] (render.h:118): DESIGN.md §1
             float px, py;
             do {
-                px = 2.0f * xw_uniform(rs) - 1.0f;
-                py = 2.0f * xw_uniform(rs) - 1.0f;
+                px = xw_uniform_2m1(rs);
+                py = xw_uniform_2m1(rs);
             } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);
         }
         V3 r_o = cam_o, r_d = camera_direction(p.cam, u, v);
