@@ -517,7 +517,10 @@ __device__ __forceinline__ float in_vgpr(float x) {
 // `traverse(d1, d2, closest, hit_idx)`: d1 = unit_vector(d0) (what the world-level ScaleRay produces),
 // d2 = unit_vector(d1) (what the triangle-level one produces; computed only if WANT_D2 — the BVH
 // world derives its own per-level directions from d1).
-template <bool FASTDIV = false, bool SKYONLY = false, bool WANT_D2 = true, class Traverse>
+// SPEC: `traverse` takes a fifth argument, a functor that runs the hit branch's rejection draws on a COPY of the stream
+// (the master wave of a shared tile calls it while the other waves trace); a lane that turns out to have hit adopts
+// the copy, a lane that missed keeps its stream as it was — the draws a pixel consumes are the same either way.
+template <bool FASTDIV = false, bool SKYONLY = false, bool WANT_D2 = true, bool SPEC = false, class Traverse>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly,
                                              const float* __restrict__ shade_n,
                                              uint32_t* __restrict__ state, float* __restrict__ rgb,
@@ -590,19 +593,35 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 
         float closest = FLT_MAX;   // double closest_so_far = t_max (FLT_MAX), hitable_list.h:82
         int hit_idx = -1;
-        traverse(d1, d2, closest, hit_idx);
+        Xorwow rs_hit = rs;        // SPEC: the stream after the hit branch's draws
+        if constexpr (SPEC) {
+            traverse(d1, d2, closest, hit_idx, [&]() {
+                float sxr, syr, szr;
+                do {
+                    sxr = xw_uniform_2m1(rs_hit);
+                    syr = xw_uniform_2m1(rs_hit);
+                    szr = xw_uniform_2m1(rs_hit);
+                } while (sxr * sxr + syr * syr + szr * szr >= 1.0f);
+            });
+        } else {
+            traverse(d1, d2, closest, hit_idx);
+        }
 
         V3 sky = sky_from_unit(d1);                                    // backgroundSky(r.direction())
         if (hit_idx >= 0) {                                            // LambertShade, render.h:75-83
             // Lambertian::scatter -> random_in_unit_sphere: only the draws matter (material.h:11-19,66)
             const float* sn = shade_n + (size_t)hit_idx * 3;           // normal after both rotate() calls
             const float snx = sn[0], sny = sn[1], snz = sn[2];         // requested before the draws: the latency overlaps them
-            float sxr, syr, szr;
-            do {
-                sxr = xw_uniform_2m1(rs);
-                syr = xw_uniform_2m1(rs);
-                szr = xw_uniform_2m1(rs);
-            } while (sxr * sxr + syr * syr + szr * szr >= 1.0f);
+            if constexpr (SPEC) {
+                rs = rs_hit;
+            } else {
+                float sxr, syr, szr;
+                do {
+                    sxr = xw_uniform_2m1(rs);
+                    syr = xw_uniform_2m1(rs);
+                    szr = xw_uniform_2m1(rs);
+                } while (sxr * sxr + syr * syr + szr * szr >= 1.0f);
+            }
             float t = d0.x * snx + d0.y * sny + d0.z * snz;            // dot(r.direction(), rec.normal)
             if (t < 0.0f) t = 0.0f;
             // attenuation * t * backgroundSky(...) * 0.2 + emitted
@@ -1478,8 +1497,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool walk_all = desc.y == kNoList;
             const int n_src = walk_all ? n_tris : (int)desc.y;
             const uint32_t* __restrict__ lst = w.pool + desc.x;
-            const int per = (n_src + WAVES - 1) / WAVES;
-            const int k0 = min(n_src, wave * per), k1 = min(n_src, k0 + per);
+            // List world: the master wave (wave 0) has no slice — it runs the rejection draws of the hit branch while the
+            // other WAVES - 1 waves trace (render_pixel<.., SPEC>).  BVH world: every wave has a slice.
+            constexpr int kSliceWaves = BVH ? WAVES : WAVES - 1;
+            const int swave = BVH ? wave : wave - 1;
+            const int per = (n_src + kSliceWaves - 1) / kSliceWaves;
+            const int k0 = (swave < 0) ? 0 : min(n_src, swave * per), k1 = (swave < 0) ? 0 : min(n_src, k0 + per);
             // local rows of the tile (tiles are 8 local rows; they never straddle a strip)
             const int hx0 = (tile_id % w.tiles_x) * 8, hly0 = (tile_id / w.tiles_x) * 8;
             const int hx1 = min(hx0 + 8, p.nx), hly1 = min(hly0 + 8, p.row_count);
@@ -1637,8 +1660,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 });
             } else if (wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
-                render_pixel<true>(p, x, ly, shade_n, state, rgb, lane_valid,
-                             [&](V3, V3 d2, float& closest, int& hit_idx) {
+                render_pixel<true, false, true, true>(p, x, ly, shade_n, state, rgb, lane_valid,
+                             [&](V3, V3 d2, float& closest, int& hit_idx, auto&& hit_branch_draws) {
                     ray_d[0][lane] = d2.x;
                     ray_d[1][lane] = d2.y;
                     ray_d[2][lane] = d2.z;
@@ -1646,8 +1669,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     long long tc0 = 0, tc1 = 0, tc2 = 0;
                     if (stats) { tc0 = (long long)clock64(); tc_setup += tc0 - tc_prev; }
                     __syncthreads();   // B1
-                    trace_slice(d2, closest, hit_idx);
-                    if (hit_idx >= 0) atomicMin(&best_key[lane], hit_key(closest, hit_idx));
+                    hit_branch_draws();   // on a copy of the stream, while the other waves trace
                     if (stats) tc1 = (long long)clock64();
                     __syncthreads();   // B2
                     if (stats) { tc2 = (long long)clock64(); tc_trace += tc1 - tc0; tc_wait += tc2 - tc1; tc_prev = tc2; }
