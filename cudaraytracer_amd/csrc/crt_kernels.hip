@@ -1516,7 +1516,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             // BVH mode: a slice of up to 64 entries is staged once like below; up to 256 entries pass through the staging
             // area in chunks of 64 per sample (candidate masks kept per chunk); tiles without a list or with longer slices
             // walk the tree, wave 0 alone.  (The unstaged walks of the list world order ties by index, not by the tree's rule.)
-            const int s_chunks = (BVH && !walk_all) ? (k1 - k0 + 63) / 64 : 1;
+            // (from the LONGEST slice, `per`: the mode must be the same for every wave of the block — the waves of a tree tile
+            // skip the per-sample barriers the others wait at; a wave with a shorter slice just stages fewer entries)
+            const int s_chunks = (BVH && !walk_all) ? (min(per, n_src) + 63) / 64 : 1;
             const bool tree_tile = BVH && (walk_all || s_chunks > 4 || !VREC);
             const bool multi = BVH && !tree_tile && s_chunks > 1;
             const int n_lds = (VREC && !walk_all && !multi && !tree_tile) ? min(64, k1 - k0) : 0;

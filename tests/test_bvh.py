@@ -311,7 +311,7 @@ def test_gpu_bvh_strips_and_list_agreement_on_the_bench_mesh(gpu, oracle, tmp_pa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,seed", [("flat", 31), ("dense", 32), ("sliver", 33), ("pile", 34)])
+@pytest.mark.parametrize("kind,seed", [("flat", 31), ("dense", 32), ("sliver", 33), ("pile", 34), ("stack", 35)])
 def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind, seed):
     """The tiled BVH mode against the per-ray tree walk and the oracle where the two conditions of a
     hit come apart: axis-aligned triangles (flat boxes: passes the triangle test, never the box —
@@ -333,6 +333,14 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
         n = 2500
         c = np.stack([rng.uniform(-0.6, 0.6, n), rng.uniform(-0.6, 0.6, n), rng.uniform(-9, -5, n)], axis=-1)
         tri = c[:, None, :] + rng.uniform(-0.5, 0.5, (n, 3, 3))
+    elif kind == "stack":
+        # 2050 large triangles behind one another, each covering the middle of the image: the central tiles hold all of them,
+        # and 2050 entries over 8 waves are slices of 257 (five staging chunks) and a last one of 251 (four) — the mode of
+        # a shared tile (staged chunks or tree walk) must not depend on the wave that looks
+        n = 2050
+        base = np.array([[-4.0, -3.0, 0.0], [4.0, -3.0, 0.0], [0.0, 5.0, 0.0]])
+        tri = base[None] + rng.uniform(-0.3, 0.3, (n, 3, 3))
+        tri[:, :, 2] += np.linspace(-30.0, -6.0, n)[:, None]
     else:
         n = 200
         c = np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), rng.uniform(-10, -5, n)], axis=-1)
@@ -348,6 +356,10 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
     ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
     after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
     for variant in (0, 1, 7):
+        if kind == "stack" and variant == 0:
+            api.tiled_stats(1)
         (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
+        if kind == "stack" and variant == 0:
+            assert api.tiled_stats(0)[6] == n                  # the scene does what it was built for: a tile with all 2050 entries
         assert np.array_equal(bits(rgb), bits(ref)), (kind, variant, int((bits(rgb) != bits(ref)).any(axis=2).sum()))
         assert np.array_equal(st[1:], after[1:]), (kind, variant)
