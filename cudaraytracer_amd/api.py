@@ -342,13 +342,14 @@ def tiled_stats(enable):
 
 
 def wave_timeline(max_waves=8192):
-    """crt_debug_wave_timeline: (n, 3) array of 100 MHz time stamps (start, end of the shared-tile phase, end) per wavefront."""
+    """crt_debug_wave_timeline: (n, 4) array per wavefront: 100 MHz time stamps (start, end of the shared-tile phase, end)
+    and entries << 32 | tile of the block's last shared tile."""
     import numpy as np
-    out = (C.c_uint64 * (3 * max_waves))()
+    out = (C.c_uint64 * (4 * max_waves))()
     n = _lib.lib().crt_debug_wave_timeline(out, max_waves)
     if n < 0:
         check(n)
-    return np.ctypeslib.as_array(out)[: 3 * n].reshape(n, 3).copy()
+    return np.ctypeslib.as_array(out)[: 4 * n].reshape(n, 4).copy()
 
 
 def audit_tiles(scene, camera, nx, ny, samples, seed=0):

@@ -148,9 +148,9 @@ hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, u
                                    hipStream_t stream);
 constexpr int kStatsWords = 48;
 constexpr int kStatsTimeline = 47;   // != 0: shade_tiles_kernel records only its timeline (below), at full speed
-constexpr int kStatsWaveSlots = 8192;                 // timeline: per wave (block * waves + wave) three 100 MHz time stamps:
-constexpr int kStatsWaveLog = kStatsWords;            // start, end of the heavy phase, end
-constexpr int kStatsTotalWords = kStatsWaveLog + 3 * kStatsWaveSlots;
+constexpr int kStatsWaveSlots = 8192;                 // timeline: per wave (block * waves + wave) four words, three 100 MHz time stamps:
+constexpr int kStatsWaveLog = kStatsWords;            // start, end of the heavy phase, end; then entries << 32 | tile of the block's last shared tile
+constexpr int kStatsTotalWords = kStatsWaveLog + 4 * kStatsWaveSlots;
 
 // BVH world (crt_bvh_kernels.hpp).  d_nodes: 2 float4 per node, preorder with skip links
 // (layout there); d_rec / d_shade_n are in leaf ("slot") order.  fast: bounded scene (host check).

@@ -1439,6 +1439,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     const bool timeline = stats_in != nullptr && stats_in[kStatsTimeline] != 0ull;
     unsigned long long* __restrict__ stats = timeline ? nullptr : stats_in;
     const unsigned long long wall0 = timeline ? (unsigned long long)wall_clock64() : 0ull;
+    unsigned long long tl_heavy = 0ull;
     __shared__ unsigned long long best_key[64];   // per pixel: min over the waves of (ordered t, index)
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
@@ -1497,6 +1498,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool walk_all = desc.y == kNoList;
             const int n_src = walk_all ? n_tris : (int)desc.y;
             const uint32_t* __restrict__ lst = w.pool + desc.x;
+            if (timeline) tl_heavy = ((unsigned long long)(unsigned)n_src << 32) | (unsigned)tile_id;
             // List world: the master wave (wave 0) has no slice — it runs the rejection draws of the hit branch while the
             // other WAVES - 1 waves trace (render_pixel<.., SPEC>).  BVH world: every wave has a slice.
             constexpr int kSliceWaves = BVH ? WAVES : WAVES - 1;
@@ -2149,9 +2151,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         const unsigned long long wall2 = (unsigned long long)wall_clock64();   // plain stores to the wave's own slot: same-address
         const unsigned gw = blockIdx.x * WAVES + (unsigned)wave;              // atomics from 6 000 waves would cost more than the kernel
         if (gw < (unsigned)kStatsWaveSlots) {
-            stats_in[kStatsWaveLog + 3 * gw + 0] = wall0;
-            stats_in[kStatsWaveLog + 3 * gw + 1] = wall1;
-            stats_in[kStatsWaveLog + 3 * gw + 2] = wall2;
+            stats_in[kStatsWaveLog + 4 * gw + 0] = wall0;
+            stats_in[kStatsWaveLog + 4 * gw + 1] = wall1;
+            stats_in[kStatsWaveLog + 4 * gw + 2] = wall2;
+            stats_in[kStatsWaveLog + 4 * gw + 3] = tl_heavy;   // the block's last shared tile: entries << 32 | tile
         }
     }
 }

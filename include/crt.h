@@ -285,8 +285,9 @@ int crt_set_kernel_variant(int variant);
  * Then enable != 0 (re)starts counting, enable == 0 stops it.  Counting costs atomics and clock
  * reads that slow the kernels down (binning 7x, shading 1.4x); enable == 2 selects the TIMELINE
  * mode instead: the shading kernel runs at full speed and every wavefront stores three time
- * stamps of the device-wide 100 MHz clock (start, end of the shared-tile phase, end), read with
- * crt_debug_wave_timeline (3 words per wavefront, index = block * waves per block + wave; returns
+ * stamps of the device-wide 100 MHz clock (start, end of the shared-tile phase, end) and
+ * (entries << 32 | tile index) of its block's last shared tile, read with
+ * crt_debug_wave_timeline (4 words per wavefront, index = block * waves per block + wave; returns
  * the number of wavefront slots copied, at most max_waves). */
 int crt_debug_tiled_stats(int enable, uint64_t *out48);
 int crt_debug_wave_timeline(uint64_t *out, int max_waves);

@@ -35,17 +35,20 @@ print("light tiles with geometry %d: list entries %.1f per tile; per-pixel candi
 
 # timeline mode: wave start / end times on the 100 MHz device clock, with the kernel's timing intact
 L.crt_debug_tiled_stats(2, None)
-for _ in range(40):   # warm clocks
-    api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d)
-torch.cuda.synchronize()
-tl = api.wave_timeline()
-tl = tl[tl[:, 2] > 0].astype(np.int64)
-t0 = tl[:, 0].min()
-start, mid, end = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0
-print("kernel ms", api.last_kernel_times())
-print("timeline of %d waves (us from the first start): last start %.1f, heavy phase ends: median %.1f p90 %.1f max %.1f, wave ends: p10 %.1f median %.1f p90 %.1f max %.1f, mean lifetime %.1f"
-      % (len(tl), start.max(), np.median(mid), np.percentile(mid, 90), mid.max(), np.percentile(end, 10), np.median(end), np.percentile(end, 90), end.max(), (end - start).mean()))
+tx = (bench.NX + 7) // 8
+for rep in range(6):
+    for _ in range(40 if rep == 0 else 7):   # warm clocks; every frame continues the RNG streams, so the frames differ
+        api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d)
+    torch.cuda.synchronize()
+    tl = api.wave_timeline()
+    tl = tl[tl[:, 2] > 0].astype(np.int64)
+    t0 = tl[:, 0].min()
+    start, mid, end = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0
+    order = np.argsort(-mid)[::8][:3]   # one wave per block
+    print("frame %d: kernel ms %.3f; heavy phase ends: median %.1f p90 %.1f max %.1f us; wave ends: p10 %.1f median %.1f max %.1f; mean lifetime %.1f; longest heavy phases: %s"
+          % (rep, api.last_kernel_times()[2], np.median(mid), np.percentile(mid, 90), mid.max(), np.percentile(end, 10), np.median(end), end.max(), (end - start).mean(),
+             "; ".join("%.0f us tile (%d, %d) %d entries" % (mid[i], (tl[i, 3] & 0xffffffff) % tx, (tl[i, 3] & 0xffffffff) // tx, tl[i, 3] >> 32) for i in order)))
 edges = np.arange(0, end.max() + 25.0, 25.0)
-print("wave ends per 25 us:", np.histogram(end, edges)[0].tolist())
-print("heavy phase ends per 25 us (waves):", np.histogram(mid, edges)[0].tolist())
+print("last frame, wave ends per 25 us:", np.histogram(end, edges)[0].tolist())
+print("last frame, heavy phase ends per 25 us (waves):", np.histogram(mid, edges)[0].tolist())
 L.crt_debug_tiled_stats(0, None)
