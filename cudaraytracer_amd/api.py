@@ -352,6 +352,16 @@ def wave_timeline(max_waves=8192):
     return np.ctypeslib.as_array(out)[: 4 * n].reshape(n, 4).copy()
 
 
+def sample_timeline():
+    """crt_debug_wave_timeline(-1): (4, 256, 2) time stamps (master's draws done, slices done) per sample of blocks 0..3."""
+    import numpy as np
+    out = (C.c_uint64 * 2048)()
+    n = _lib.lib().crt_debug_wave_timeline(out, -1)
+    if n < 0:
+        check(n)
+    return np.ctypeslib.as_array(out).reshape(4, 256, 2).copy()
+
+
 def audit_tiles(scene, camera, nx, ny, samples, seed=0):
     """crt_debug_audit_tiles: (passing pairs, pairs missing from a tile list, cull-sure violations, offender)."""
     out = (C.c_uint64 * 4)()

@@ -150,7 +150,9 @@ constexpr int kStatsWords = 48;
 constexpr int kStatsTimeline = 47;   // != 0: shade_tiles_kernel records only its timeline (below), at full speed
 constexpr int kStatsWaveSlots = 8192;                 // timeline: per wave (block * waves + wave) four words, three 100 MHz time stamps:
 constexpr int kStatsWaveLog = kStatsWords;            // start, end of the heavy phase, end; then entries << 32 | tile of the block's last shared tile
-constexpr int kStatsTotalWords = kStatsWaveLog + 4 * kStatsWaveSlots;
+constexpr int kStatsSampleBlocks = 4, kStatsSampleSlots = 256;   // timeline: blocks 0..3 log (draws done, slices done) per sample
+constexpr int kStatsSampleLog = kStatsWaveLog + 4 * kStatsWaveSlots;
+constexpr int kStatsTotalWords = kStatsSampleLog + 2 * kStatsSampleBlocks * kStatsSampleSlots;
 
 // BVH world (crt_bvh_kernels.hpp).  d_nodes: 2 float4 per node, preorder with skip links
 // (layout there); d_rec / d_shade_n are in leaf ("slot") order.  fast: bounded scene (host check).

@@ -454,6 +454,16 @@ __device__ __forceinline__ void walk_list(const float* __restrict__ rec, const u
         walk<FAST>(rec, 0, n, [&](int k) { return __builtin_amdgcn_readlane(mine, k); }, d, closest, hit_idx);
     }
 }
+// the same for the entries first + j * step, j in [j0, j1)
+template <bool FAST>
+__device__ __forceinline__ void walk_list_strided(const float* __restrict__ rec, const uint32_t* __restrict__ lst, int first, int step,
+                                                  int j0, int j1, int lane, V3 d, float& closest, int& hit_idx) {
+    for (int base = j0; base < j1; base += 64) {
+        const int n = min(64, j1 - base);
+        const int mine = (lane < n) ? (int)lst[first + (base + lane) * step] : 0;
+        walk<FAST>(rec, 0, n, [&](int k) { return __builtin_amdgcn_readlane(mine, k); }, d, closest, hit_idx);
+    }
+}
 
 // ---- the same test with the record in VGPRs.  On gfx950 a VALU instruction with an SGPR
 // operand issues at half the rate of a VGPR-only one (profiles/r1_ubench_valu*.txt).  For
@@ -1498,13 +1508,20 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool walk_all = desc.y == kNoList;
             const int n_src = walk_all ? n_tris : (int)desc.y;
             const uint32_t* __restrict__ lst = w.pool + desc.x;
-            if (timeline) tl_heavy = ((unsigned long long)(unsigned)n_src << 32) | (unsigned)tile_id;
+            if (timeline) tl_heavy = ((unsigned long long)(unsigned)n_src << 24) | (unsigned)tile_id;
             // List world: the master wave (wave 0) has no slice — it runs the rejection draws of the hit branch while the
             // other WAVES - 1 waves trace (render_pixel<.., SPEC>).  BVH world: every wave has a slice.
             constexpr int kSliceWaves = BVH ? WAVES : WAVES - 1;
             const int swave = BVH ? wave : wave - 1;
             const int per = (n_src + kSliceWaves - 1) / kSliceWaves;
             const int k0 = (swave < 0) ? 0 : min(n_src, swave * per), k1 = (swave < 0) ? 0 : min(n_src, k0 + per);
+            // Tiles with a list: the slices are INTERLEAVED (wave s takes entries s, s + 7, s + 14, ...).  Neighbours in a
+            // tile's list are neighbours in the mesh and cover the same pixels; dealt round-robin, every slice gets its share
+            // of the (pixel, entry) pairs, and none overflows its pair buffer while the others idle at the barrier (measured:
+            // with contiguous slices the 247-entry pole tiles took 245 or 640 us depending on the order the binning's
+            // atomics happened to leave the list in — and ended the launch in the second case).
+            const bool interleaved = !walk_all;
+            const int cnt_w = (!interleaved || swave < 0 || swave >= n_src) ? 0 : (n_src - swave + kSliceWaves - 1) / kSliceWaves;
             // local rows of the tile (tiles are 8 local rows; they never straddle a strip)
             const int hx0 = (tile_id % w.tiles_x) * 8, hly0 = (tile_id / w.tiles_x) * 8;
             const int hx1 = min(hx0 + 8, p.nx), hly1 = min(hly0 + 8, p.row_count);
@@ -1523,11 +1540,11 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const int s_chunks = (BVH && !walk_all) ? (min(per, n_src) + 63) / 64 : 1;
             const bool tree_tile = BVH && (walk_all || s_chunks > 4 || !VREC);
             const bool multi = BVH && !tree_tile && s_chunks > 1;
-            const int n_lds = (VREC && !walk_all && !multi && !tree_tile) ? min(64, k1 - k0) : 0;
+            const int n_lds = (VREC && !walk_all && !multi && !tree_tile) ? min(64, cnt_w) : 0;
             int slice_mine = 0;
             Cand cand = {0u, 0u, 0u, 0u};
             if (n_lds > 0) {   // per-pixel candidates among the staged entries of this wave's slice
-                slice_mine = (lane < n_lds) ? (int)lst[k0 + lane] : 0;
+                slice_mine = (lane < n_lds) ? (int)lst[swave + lane * kSliceWaves] : 0;
                 stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
                                  global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
             }
@@ -1540,8 +1557,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if (c < s_chunks) {
-                        const int n = min(64, k1 - k0 - 64 * c);
-                        e_c[c] = (lane < n) ? (int)lst[k0 + 64 * c + lane] : 0;
+                        const int n = min(64, cnt_w - 64 * c);
+                        e_c[c] = (lane < n) ? (int)lst[swave + (64 * c + lane) * kSliceWaves] : 0;
                         stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, e_c[c], n, lane, x, gy, cc[c]);
                         if (!lane_valid) cc[c].lo = cc[c].hi = 0u;
                         q_c[c] = (lane < n) ? (int)(((unsigned)e_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bvh->partner[e_c[c] & 0x7fffffff])) : 0;
@@ -1566,7 +1583,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                   for (int c = 0; c < 4; ++c) {
                       if (c >= s_chunks) continue;
                       __builtin_amdgcn_wave_barrier();
-                      if (lane < min(64, k1 - k0 - 64 * c)) {
+                      if (lane < min(64, cnt_w - 64 * c)) {
                           const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(e_c[c] & 0x7fffffff) * kRecFloats);
                           lrec[wave][0][lane] = r[0]; lrec[wave][1][lane] = r[1]; lrec[wave][2][lane] = r[2]; lrec[wave][3][lane] = r[3];
                           lent[wave][lane] = q_c[c];
@@ -1583,8 +1600,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     trace_pairs(lrec[wave], lent[wave], lpairs[wave], slice_pairs, lane,
                                 [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key);
                 else if (n_lds > 0) trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
-                if (!walk_all) walk_list<true>(rec, lst, k0 + n_lds, k1, lane, d2, closest, hit_idx);
-                else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);
+                if (interleaved) walk_list_strided<true>(rec, lst, swave, kSliceWaves, n_lds, cnt_w, lane, d2, closest, hit_idx);
+                else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);   // no list: a range of all triangles
               }
             };
             if (BVH && tree_tile) {
@@ -1664,6 +1681,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 });
             } else if (wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
+                int tl_sample = 0;   // timeline mode: the first blocks log two time stamps per sample of their first shared tile
                 render_pixel<true, false, true, true>(p, x, ly, shade_n, state, rgb, lane_valid,
                              [&](V3, V3 d2, float& closest, int& hit_idx, auto&& hit_branch_draws) {
                     ray_d[0][lane] = d2.x;
@@ -1674,9 +1692,16 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     if (stats) { tc0 = (long long)clock64(); tc_setup += tc0 - tc_prev; }
                     __syncthreads();   // B1
                     hit_branch_draws();   // on a copy of the stream, while the other waves trace
+                    if (timeline && blockIdx.x < (unsigned)kStatsSampleBlocks && lane == 0 && tl_sample < kStatsSampleSlots) {
+                        stats_in[kStatsSampleLog + (blockIdx.x * kStatsSampleSlots + tl_sample) * 2 + 0] = (unsigned long long)wall_clock64();   // draws done
+                    }
                     if (stats) tc1 = (long long)clock64();
                     __syncthreads();   // B2
                     if (stats) { tc2 = (long long)clock64(); tc_trace += tc1 - tc0; tc_wait += tc2 - tc1; tc_prev = tc2; }
+                    if (timeline && blockIdx.x < (unsigned)kStatsSampleBlocks && lane == 0 && tl_sample < kStatsSampleSlots) {
+                        stats_in[kStatsSampleLog + (blockIdx.x * kStatsSampleSlots + tl_sample) * 2 + 1] = (unsigned long long)wall_clock64();   // slices done
+                        ++tl_sample;
+                    }
                     const unsigned long long kbest = best_key[lane];
                     hit_idx = (kbest == ~0ull) ? -1 : (int)(unsigned)(kbest & 0xffffffffull);
                 });
@@ -2154,7 +2179,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             stats_in[kStatsWaveLog + 4 * gw + 0] = wall0;
             stats_in[kStatsWaveLog + 4 * gw + 1] = wall1;
             stats_in[kStatsWaveLog + 4 * gw + 2] = wall2;
-            stats_in[kStatsWaveLog + 4 * gw + 3] = tl_heavy;   // the block's last shared tile: entries << 32 | tile
+            // the block's last shared tile: entries << 44 | tile << 20, and the wave's place (HW_REG_HW_ID: wave, SIMD, CU, SE)
+            stats_in[kStatsWaveLog + 4 * gw + 3] = (tl_heavy << 20) | (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xfffffu);
         }
     }
 }

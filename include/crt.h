@@ -286,9 +286,11 @@ int crt_set_kernel_variant(int variant);
  * reads that slow the kernels down (binning 7x, shading 1.4x); enable == 2 selects the TIMELINE
  * mode instead: the shading kernel runs at full speed and every wavefront stores three time
  * stamps of the device-wide 100 MHz clock (start, end of the shared-tile phase, end) and
- * (entries << 32 | tile index) of its block's last shared tile, read with
+ * (entries << 44 | tile index << 20 | HW_REG_HW_ID[19:0]) of its block's last shared tile, read with
  * crt_debug_wave_timeline (4 words per wavefront, index = block * waves per block + wave; returns
- * the number of wavefront slots copied, at most max_waves). */
+ * the number of wavefront slots copied, at most max_waves).  max_waves == -1 reads the per-sample
+ * log of blocks 0..3 instead (their first shared tile, list world): 4 x 256 pairs of time stamps
+ * (master's draws done, slices done); `out` then holds 2048 words. */
 int crt_debug_tiled_stats(int enable, uint64_t *out48);
 int crt_debug_wave_timeline(uint64_t *out, int max_waves);
 

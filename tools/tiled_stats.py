@@ -47,7 +47,19 @@ for rep in range(6):
     order = np.argsort(-mid)[::8][:3]   # one wave per block
     print("frame %d: kernel ms %.3f; heavy phase ends: median %.1f p90 %.1f max %.1f us; wave ends: p10 %.1f median %.1f max %.1f; mean lifetime %.1f; longest heavy phases: %s"
           % (rep, api.last_kernel_times()[2], np.median(mid), np.percentile(mid, 90), mid.max(), np.percentile(end, 10), np.median(end), end.max(), (end - start).mean(),
-             "; ".join("%.0f us tile (%d, %d) %d entries" % (mid[i], (tl[i, 3] & 0xffffffff) % tx, (tl[i, 3] & 0xffffffff) // tx, tl[i, 3] >> 32) for i in order)))
+             "; ".join("%.0f us tile (%d, %d) %d entries" % (mid[i], ((tl[i, 3] >> 20) & 0xffffff) % tx, ((tl[i, 3] >> 20) & 0xffffff) // tx, tl[i, 3] >> 44) for i in order)))
+    hw = tl[:, 3] & 0xfffff                      # HW_REG_HW_ID: wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13]
+    simd = ((hw >> 4) & 3).reshape(-1, 8)        # per block
+    per_simd = np.stack([(simd == k).sum(axis=1) for k in range(4)], axis=1)
+    print("   waves of a block per SIMD: blocks by their most crowded SIMD: %s; block 0: %s, block 1: %s"
+          % (np.bincount(per_simd.max(axis=1), minlength=9).tolist(), per_simd[0].tolist(), per_simd[1].tolist()))
+    sl = api.sample_timeline().astype(np.int64)
+    for b in range(2):
+        t_b2 = sl[b, :spp, 1]
+        per = np.diff(t_b2) / 100.0
+        wait = (sl[b, :spp, 1] - sl[b, :spp, 0]) / 100.0
+        print("   block %d per-sample us: median %.2f max %.2f (sample %d), samples over 3x the median: %d; master's wait for the slices after its draws: median %.2f max %.2f"
+              % (b, np.median(per), per.max(), int(per.argmax()) + 1, int((per > 3 * np.median(per)).sum()), np.median(wait), wait.max()))
 edges = np.arange(0, end.max() + 25.0, 25.0)
 print("last frame, wave ends per 25 us:", np.histogram(end, edges)[0].tolist())
 print("last frame, heavy phase ends per 25 us (waves):", np.histogram(mid, edges)[0].tolist())
