@@ -2125,6 +2125,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             n_pairs = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
         }
         const bool pair_mode = n_pairs != 0xffffffffu;
+        if (stats && VREC && cnt > 0 && lane == 0) {   // diagnostics: did the pairs fit, how many
+            if (pair_mode) atomicAdd(&stats[42], (unsigned long long)n_pairs);
+            else atomicAdd(&stats[41], 1ull);
+        }
         if (cnt == 0) {   // background only (most tiles of a typical frame)
             if (x < p.nx && ly < p.row_count) render_sky_pixel(p, x, ly, state, rgb);
         } else if (pair_mode) {   // all 64 lanes stay active (ds_bpermute reads lanes); off-image lanes replay a valid pixel, unstored
@@ -2403,7 +2407,8 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (d_bvh_tiles) {   // the tree as the world (shade_tiles_kernel<.., BVH = true>)
         group = 8;
 #ifndef CRT_BVH_OCC
-#define CRT_BVH_OCC 6   // measured (profiles/r2_tiled/sweep_bvh.txt): 6 waves/SIMD with batches of 4 boxes beat 4 waves/SIMD with 8
+#define CRT_BVH_OCC 4   // the block's 62 KB of LDS allow two blocks per CU = 4 waves/SIMD; asked for 6, the compiler gives up on the
+                        // target and takes 220 VGPRs = 2 waves/SIMD (C3 2.46 ms, C5 17.0); held to 128 VGPRs: 1.70 / 10.5 ms (sweep_bvh.txt)
 #endif
         fn = shade_tiles_kernel<true, CRT_BVH_OCC, 8, true>;
         if (bvh_force_general) dbg_repeat = -77;

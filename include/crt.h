@@ -281,7 +281,8 @@ int crt_set_kernel_variant(int variant);
  *   master wave of shared tiles: [32] set-up+merge+shade, [33] own trace, [34] wait at the
  *   second barrier (cycles summed over [35] tiles with [36] survivors in total);
  *   per-pixel candidate masks of the light tiles with geometry: [37] tiles, [38] their list
- *   entries, [39] sum of the longest per-pixel candidate list of each, [40] sum of all lists.
+ *   entries, [39] sum of the longest per-pixel candidate list of each, [40] sum of all lists,
+ *   [41] tiles whose (pixel, entry) pairs did not fit the pair buffer, [42] pairs of the others.
  * Then enable != 0 (re)starts counting, enable == 0 stops it.  Counting costs atomics and clock
  * reads that slow the kernels down (binning 7x, shading 1.4x); enable == 2 selects the TIMELINE
  * mode instead: the shading kernel runs at full speed and every wavefront stores three time

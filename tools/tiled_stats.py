@@ -31,7 +31,8 @@ print("shade kernel cycles: heavy phase sum over blocks %d max %d | light phase 
 print("bin busiest wavefront: regions %d, tiles box-tested %d, cycles %d" % tuple(o[29:32]))
 print("heavy tiles %d (sum survivors %d): master wave cycles per tile: setup+merge+shade %.0f, own trace %.0f, wait B2 %.0f" % (o[35], o[36], o[32]/max(o[35],1), o[33]/max(o[35],1), o[34]/max(o[35],1)))
 print("kernel ms", api.last_kernel_times())
-print("light tiles with geometry %d: list entries %.1f per tile; per-pixel candidates: longest of the wavefront %.1f, mean %.2f" % (o[37], o[38] / max(o[37], 1), o[39] / max(o[37], 1), o[40] / max(o[37], 1) / 64.0))
+print("light tiles with geometry %d: list entries %.1f per tile; per-pixel candidates: longest of the wavefront %.1f, mean %.2f; pair buffer overflowed in %d tiles, %.0f pairs per tile otherwise"
+      % (o[37], o[38] / max(o[37], 1), o[39] / max(o[37], 1), o[40] / max(o[37], 1) / 64.0, o[41], o[42] / max(o[37] - o[41], 1)))
 
 # timeline mode: wave start / end times on the 100 MHz device clock, with the kernel's timing intact
 L.crt_debug_tiled_stats(2, None)
