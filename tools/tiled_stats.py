@@ -12,14 +12,17 @@ import bench
 from cudaraytracer_amd import _lib, api
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+BVH = len(sys.argv) > 2 and sys.argv[2] == "bvh"   # the BVHNode world through the tiled kernels
 obj = bench.build_scene_obj(tempfile.mkdtemp())
 scene = api.Scene.from_obj(obj, scale=1.0)
 cam = api.init_camera(bench.NX, bench.NY)
 st = api.SetCurandState(bench.NX, bench.NY)
+if BVH:
+    api.create_BVHfromList(scene, st)
 d = torch.zeros(bench.NX * bench.NY * 3, device="cuda")
 L = _lib.lib()
 L.crt_debug_tiled_stats(1, None)
-api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d)
+api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d, bvh=BVH)
 torch.cuda.synchronize()
 out = (C.c_uint64 * 48)()
 L.crt_debug_tiled_stats(0, out)
@@ -39,7 +42,7 @@ L.crt_debug_tiled_stats(2, None)
 tx = (bench.NX + 7) // 8
 for rep in range(6):
     for _ in range(40 if rep == 0 else 7):   # warm clocks; every frame continues the RNG streams, so the frames differ
-        api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d)
+        api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d, bvh=BVH)
     torch.cuda.synchronize()
     tl = api.wave_timeline()
     tl = tl[tl[:, 2] > 0].astype(np.int64)
