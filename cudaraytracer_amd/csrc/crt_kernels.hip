@@ -1509,10 +1509,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const int n_src = walk_all ? n_tris : (int)desc.y;
             const uint32_t* __restrict__ lst = w.pool + desc.x;
             if (timeline) tl_heavy = ((unsigned long long)(unsigned)n_src << 24) | (unsigned)tile_id;
-            // The master wave (wave 0) has no slice — it runs the rejection draws of the hit branch while the other
-            // WAVES - 1 waves trace (render_pixel<.., SPEC>).
-            constexpr int kSliceWaves = WAVES - 1;
-            const int swave = wave - 1;
+            // List world: the master wave (wave 0) has no slice — it runs the rejection draws of the hit branch while the
+            // other WAVES - 1 waves trace (render_pixel<.., SPEC>).  BVH world: every wave has a slice (seven slices would
+            // push the 1 800-2 000-entry pole tiles of C5 past four staging chunks per wave, i.e. to the tree walk: 10 -> 47 ms;
+            // and the draws are not what a shared BVH tile waits for — the winner's chain of boxes is).
+            constexpr int kSliceWaves = BVH ? WAVES : WAVES - 1;
+            const int swave = BVH ? wave : wave - 1;
             const int per = (n_src + kSliceWaves - 1) / kSliceWaves;
             const int k0 = (swave < 0) ? 0 : min(n_src, swave * per), k1 = (swave < 0) ? 0 : min(n_src, k0 + per);
             // Tiles with a list: the slices are INTERLEAVED (wave s takes entries s, s + 7, s + 14, ...).  Neighbours in a
@@ -1626,8 +1628,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, hly0));
                 const int first_level = __builtin_amdgcn_readfirstlane(
                     tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[0], lane));
-                render_pixel<true, false, false, true>(p, x, ly, shade_n, state, rgb, lane_valid,
-                                                       [&](V3 d1, V3, float& closest, int& hit_idx, auto&& hit_branch_draws) {
+                render_pixel<true, false, false>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     const V3 c1 = rot0_exact(bt.rot, d1);
                     const V3 c2 = chain_next<true>(bt.rot, c1);
                     const V3 c3 = chain_next<true>(bt.rot, c2);
@@ -1640,7 +1641,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     ray_d[2][lane] = c3.z;
                     best_key[lane] = ~0ull;
                     __syncthreads();   // B1
-                    hit_branch_draws();   // on a copy of the stream, while the other waves trace
+                    int q = -1;
+                    float tb = FLT_MAX;
+                    trace_slice(c3, tb, q);
+                    if (q >= 0) atomicMin(&best_key[lane], hit_key(tb, q));
                     __syncthreads();   // B2
                     const unsigned long long kbest = best_key[lane];
                     int slot = -1;

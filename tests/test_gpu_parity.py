@@ -447,3 +447,26 @@ def test_tiled_equals_brute_force_with_shuffled_triangle_order(gpu, crt_built):
     assert np.array_equal(outs[0][1], outs[1][1])
     n_pass, n_missing, n_cull, _ = api.audit_tiles(scene, cam, nx, ny, 2)
     assert n_pass > 0 and n_missing == 0 and n_cull == 0
+
+
+@pytest.mark.gpu
+def test_diagnostics_do_not_change_pixels(gpu, crt_built):
+    """crt_debug_tiled_stats: neither the counters (mode 1) nor the wave timeline (mode 2) may touch
+    pixels or RNG states; the timeline has one record per wavefront with start <= end of the
+    shared-tile phase <= end."""
+    sc = scenes.displaced_sphere(60, 80)
+    nx, ny, spp = 320, 200, 3
+    scene, cam = make(sc, nx, ny)
+    (ref,), st_ref = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+    for mode in (1, 2):
+        api.tiled_stats(mode)
+        try:
+            (o,), st = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+            tl = api.wave_timeline() if mode == 2 else None
+        finally:
+            api.tiled_stats(0)
+        assert np.array_equal(bits(o), bits(ref)) and np.array_equal(st, st_ref), mode
+        if tl is not None:
+            tl = tl[tl[:, 2] > 0].astype(np.int64)
+            assert len(tl) > 0 and len(tl) % 8 == 0
+            assert np.all(tl[:, 0] <= tl[:, 1]) and np.all(tl[:, 1] <= tl[:, 2])
