@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Print the tiled kernel's survivor statistics for the bench scene (run on the GPU box)."""
+"""Print the tiled kernels' survivor statistics, cycle accounting and wave timeline (run on the GPU box).
+usage: tiled_stats.py [spp] [list|bvh] [C3|C4|C5]   (default: the bench frame C3, list world)"""
 import ctypes as C
 import os
 import sys
@@ -13,16 +14,18 @@ from cudaraytracer_amd import _lib, api
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 BVH = len(sys.argv) > 2 and sys.argv[2] == "bvh"   # the BVHNode world through the tiled kernels
-obj = bench.build_scene_obj(tempfile.mkdtemp())
+from cudaraytracer_amd import scenes
+FRAME = sys.argv[3] if len(sys.argv) > 3 else bench.FRAME
+obj, NX, NY, _ = scenes.baseline_obj(FRAME, tempfile.mkdtemp())
 scene = api.Scene.from_obj(obj, scale=1.0)
-cam = api.init_camera(bench.NX, bench.NY)
-st = api.SetCurandState(bench.NX, bench.NY)
+cam = api.init_camera(NX, NY)
+st = api.SetCurandState(NX, NY)
 if BVH:
     api.create_BVHfromList(scene, st)
-d = torch.zeros(bench.NX * bench.NY * 3, device="cuda")
+d = torch.zeros(NX * NY * 3, device="cuda")
 L = _lib.lib()
 L.crt_debug_tiled_stats(1, None)
-api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d, bvh=BVH)
+api.render_rows(scene, cam, st, NX, NY, spp, 0, NY, d, bvh=BVH)
 torch.cuda.synchronize()
 out = (C.c_uint64 * 48)()
 L.crt_debug_tiled_stats(0, out)
@@ -39,10 +42,10 @@ print("light tiles with geometry %d: list entries %.1f per tile; per-pixel candi
 
 # timeline mode: wave start / end times on the 100 MHz device clock, with the kernel's timing intact
 L.crt_debug_tiled_stats(2, None)
-tx = (bench.NX + 7) // 8
+tx = (NX + 7) // 8
 for rep in range(6):
-    for _ in range(40 if rep == 0 else 7):   # warm clocks; every frame continues the RNG streams, so the frames differ
-        api.render_rows(scene, cam, st, bench.NX, bench.NY, spp, 0, bench.NY, d, bvh=BVH)
+    for _ in range((40 if rep == 0 else 7) if NX * NY < 4000000 else 3):   # warm clocks; every frame continues the RNG streams, so the frames differ
+        api.render_rows(scene, cam, st, NX, NY, spp, 0, NY, d, bvh=BVH)
     torch.cuda.synchronize()
     tl = api.wave_timeline()
     tl = tl[tl[:, 2] > 0].astype(np.int64)
