@@ -189,3 +189,29 @@ def test_cpp_driver_program(gpu, oracle, tmp_path):
     assert np.array_equal(decode_png(os.path.join(out, "picture_0.png")), oracle.to_rgba8(ref))
     rows = open(csv).read().splitlines()
     assert rows[0] == "frame,rendering,update,build" and rows[1].startswith(",,,") and rows[2].startswith("0,") and rows[3].startswith("1,")
+
+
+def test_bench_under_torchrun_two_ranks_sharing_the_gpu(gpu):
+    """The driver's N>1 launch line (python -m torch.distributed.run ... bench.py --gpus N) with two ranks on the one GPU
+    of the test box (CRT_BENCH_SHARE_GPU=1: gloo instead of RCCL, same strips, same gather, same reassembly kernel):
+    rank 0 prints ONE JSON line for the whole job."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CRT_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--spp", "4",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
+    assert "strips" in out["config"]["parallelism"]
