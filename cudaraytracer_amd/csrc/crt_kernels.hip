@@ -1628,6 +1628,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, hly0));
                 const int first_level = __builtin_amdgcn_readfirstlane(
                     tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[0], lane));
+                int tl_sample_bvh = 0;   // timeline mode: (slices done, chains checked) per sample of the first blocks' first tile
                 render_pixel<true, false, false>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     const V3 c1 = rot0_exact(bt.rot, d1);
                     const V3 c2 = chain_next<true>(bt.rot, c1);
@@ -1646,6 +1647,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     trace_slice(c3, tb, q);
                     if (q >= 0) atomicMin(&best_key[lane], hit_key(tb, q));
                     __syncthreads();   // B2
+                    if (timeline && blockIdx.x < (unsigned)kStatsSampleBlocks && lane == 0 && tl_sample_bvh < kStatsSampleSlots)
+                        stats_in[kStatsSampleLog + (blockIdx.x * kStatsSampleSlots + tl_sample_bvh) * 2 + 0] = (unsigned long long)wall_clock64();   // slices done
                     const unsigned long long kbest = best_key[lane];
                     int slot = -1;
                     bool alone = !hot;
@@ -1680,6 +1683,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     }
                     hit_idx = slot;
                     closest = 0.0f;
+                    if (timeline && blockIdx.x < (unsigned)kStatsSampleBlocks && lane == 0 && tl_sample_bvh < kStatsSampleSlots) {
+                        stats_in[kStatsSampleLog + (blockIdx.x * kStatsSampleSlots + tl_sample_bvh) * 2 + 1] = (unsigned long long)wall_clock64();   // winners' chains checked
+                        ++tl_sample_bvh;
+                    }
                 });
             } else if (wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;

@@ -65,6 +65,11 @@ for rep in range(6):
         t_b2 = sl[b, :spp, 1]
         per = np.diff(t_b2) / 100.0
         wait = (sl[b, :spp, 1] - sl[b, :spp, 0]) / 100.0
+        if BVH:   # stamps: slices done (after B2), winners' chains checked
+            per = np.diff(sl[b, :spp, 0]) / 100.0
+            print("   block %d per-sample us: median %.2f max %.2f; of which the master's chain checks after the slices: median %.2f max %.2f"
+                  % (b, np.median(per), per.max(), np.median(wait), wait.max()))
+            continue
         print("   block %d per-sample us: median %.2f max %.2f (sample %d), samples over 3x the median: %d; master's wait for the slices after its draws: median %.2f max %.2f"
               % (b, np.median(per), per.max(), int(per.argmax()) + 1, int((per > 3 * np.median(per)).sum()), np.median(wait), wait.max()))
 edges = np.arange(0, end.max() + 25.0, 25.0)
