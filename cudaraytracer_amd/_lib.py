@@ -88,6 +88,7 @@ PROTOTYPES = {
     "crt_render": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.POINTER(CrtCamera), C.c_uint64, _fp]),
     "crt_set_kernel_variant": (C.c_int, [C.c_int]),
+    "crt_set_kernel_timing": (C.c_int, [C.c_int]),
     "crt_debug_tiled_stats": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "crt_debug_wave_timeline": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "crt_debug_check_reciprocal": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint64)]),

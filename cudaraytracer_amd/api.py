@@ -326,6 +326,11 @@ def last_kernel_ms():
     return ms
 
 
+def set_kernel_timing(enable):
+    """crt_set_kernel_timing: the per-frame HIP events behind last_kernel_times (per thread); returns the previous value."""
+    return bool(_lib.lib().crt_set_kernel_timing(1 if enable else 0))
+
+
 def last_kernel_times():
     """(total_ms, bin_ms, shade_ms) of the last render_rows on this thread."""
     out = (C.c_float * 3)()

@@ -43,6 +43,7 @@ int crt::set_error(int code, const char* fmt, ...) {
 namespace {
 
 thread_local int g_variant = 0;
+thread_local bool g_timing = true;   // crt_set_kernel_timing: record the HIP events behind crt_last_kernel_times
 thread_local unsigned long long* g_d_stats = nullptr;   // device counters when stats are enabled
 
 
@@ -619,6 +620,12 @@ int crt_set_kernel_variant(int variant) {
     return prev;
 }
 
+int crt_set_kernel_timing(int enable) {
+    const int prev = g_timing ? 1 : 0;
+    g_timing = enable != 0;
+    return prev;
+}
+
 namespace {
 // world: 0 = the triangle list (renderListAnimation, render.h:179), 1 = the BVH over it (renderBVHAnimation, render.h:222)
 int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny, int samples,
@@ -775,7 +782,8 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         HIP_TRY(hipEventCreate(&cx.ev_stop));
         HIP_TRY(hipEventCreate(&cx.ev_mid));
     }
-    HIP_TRY(hipEventRecord(cx.ev_start, stream));   // the per-frame prepasses count as binning time
+    const bool timing = g_timing;   // three marker packets per frame: a host that never asks for kernel times can switch them off
+    if (timing) HIP_TRY(hipEventRecord(cx.ev_start, stream));   // the per-frame prepasses count as binning time
 
     // public variant numbering (crt_set_kernel_variant): 0 auto, 1 brute force, 2 tiled,
     // 3 tiled with tiny list capacities (exercises the overflow fallbacks)
@@ -825,8 +833,8 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
                                            t ? t->d_nodes : nullptr, t ? t->n_nodes : 0, rot, rng->d_state, d_rgb, world == 1, fast,
                                            shader, max_depth, force_mode, stream));
         cx.ev_has_mid = false;
-        HIP_TRY(hipEventRecord(cx.ev_stop, stream));
-        cx.ev_valid = true;
+        if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
+        cx.ev_valid = timing;
         return CRT_OK;
     }
     if (world == 1) {
@@ -846,11 +854,11 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
             if (rc != CRT_OK) return rc;
             HIP_TRY(crt::launch_frame_prepass(scene->bvh->d_base_slots, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
             HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, 1, &cx.w,
-                                       cx.n_cus, true, g_d_stats, cx.ev_mid, &cx.cache_bvh, true, stream,
+                                       cx.n_cus, true, g_d_stats, timing ? cx.ev_mid : nullptr, &cx.cache_bvh, true, stream,
                                        static_cast<const crt::BvhTiles*>(scene->bvh->d_tiles_view), g_variant == 7));
             cx.ev_has_mid = true;
-            HIP_TRY(hipEventRecord(cx.ev_stop, stream));
-            cx.ev_valid = true;
+            if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
+            cx.ev_valid = timing;
             return CRT_OK;
         }
         HIP_TRY(crt::launch_tri_prepass(scene->bvh->d_base_slots, scene->n_tris, camera->origin, cx.d_rec, stream));
@@ -858,8 +866,8 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         HIP_TRY(crt::launch_render_bvh(p, scene->bvh->d_nodes, scene->bvh->n_nodes, scene->bvh->rot, cx.d_rec,
                                        scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, fast, force_mode, stream));
         cx.ev_has_mid = false;
-        HIP_TRY(hipEventRecord(cx.ev_stop, stream));
-        cx.ev_valid = true;
+        if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
+        cx.ev_valid = timing;
         return CRT_OK;
     }
     if (kernel_variant != 0) {   // one launch: exact + classification records, scratch zeroed
@@ -871,11 +879,11 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     }
     HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
                                d_rgb, kernel_variant, kernel_variant ? &cx.w : nullptr, cx.n_cus,
-                               scene->tiled_safe && cam_ok, g_d_stats, kernel_variant ? cx.ev_mid : nullptr, &cx.cache,
+                               scene->tiled_safe && cam_ok, g_d_stats, (kernel_variant && timing) ? cx.ev_mid : nullptr, &cx.cache,
                                kernel_variant != 0, stream));
     cx.ev_has_mid = kernel_variant != 0;
-    HIP_TRY(hipEventRecord(cx.ev_stop, stream));
-    cx.ev_valid = true;
+    if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
+    cx.ev_valid = timing;
     return CRT_OK;
 }
 }  // namespace
@@ -1010,7 +1018,7 @@ int crt_last_kernel_times(float* ms3) {
     // launch stream of that call.
     if (!ms3) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: null output");
     Context* cx = g_last_ctx;
-    if (!cx || !cx->ev_valid) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: no kernel launched on this thread");
+    if (!cx || !cx->ev_valid) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: no timed kernel launched on this thread (crt_set_kernel_timing)");
     std::lock_guard<std::mutex> lock(cx->mu);
     HIP_TRY(hipEventSynchronize(cx->ev_stop));
     HIP_TRY(hipEventElapsedTime(&ms3[0], cx->ev_start, cx->ev_stop));

@@ -327,9 +327,16 @@ int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t *mismatc
  * library on the calling thread, measured with HIP events on the launch stream.
  * Synchronises on that stream.  Negative on error. */
 float crt_last_kernel_ms(void);
+
 /* Same measurement split per kernel: ms3[0] = total, ms3[1] = binning kernel (0 for the
  * brute-force variant), ms3[2] = shading / brute-force kernel. */
 int crt_last_kernel_times(float *ms3);
+
+/* The three HIP events per frame behind crt_last_kernel_ms / crt_last_kernel_times (per calling
+ * thread, default on).  Each is a marker packet between the frame's five kernels; a host that never
+ * asks for kernel times can switch them off (bench.py does for its timed region: -7 us per frame).
+ * While off, crt_last_kernel_* fail with CRT_ERR_INVALID.  Returns the previous value. */
+int crt_set_kernel_timing(int enable);
 
 /* ---- multi-GPU ------------------------------------------------------------------
  * The reference is single-GPU; this section is the north-star split: strips of

@@ -470,3 +470,24 @@ def test_diagnostics_do_not_change_pixels(gpu, crt_built):
             tl = tl[tl[:, 2] > 0].astype(np.int64)
             assert len(tl) > 0 and len(tl) % 8 == 0
             assert np.all(tl[:, 0] <= tl[:, 1]) and np.all(tl[:, 1] <= tl[:, 2])
+
+
+@pytest.mark.gpu
+def test_kernel_timing_can_be_switched_off(gpu, crt_built):
+    """crt_set_kernel_timing(0): no event markers between a frame's kernels, same pixels, and
+    crt_last_kernel_times says so instead of returning stale numbers."""
+    sc = scenes.displaced_sphere(40, 50)
+    nx, ny, spp = 160, 96, 2
+    scene, cam = make(sc, nx, ny)
+    (ref,), st_ref = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+    assert api.last_kernel_times()[0] > 0.0
+    prev = api.set_kernel_timing(False)
+    try:
+        (o,), st = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+        with pytest.raises(api.CrtError):
+            api.last_kernel_times()
+    finally:
+        api.set_kernel_timing(prev)
+    assert np.array_equal(bits(o), bits(ref)) and np.array_equal(st, st_ref)
+    hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+    assert api.last_kernel_times()[0] > 0.0
