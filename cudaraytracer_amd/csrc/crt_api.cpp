@@ -696,6 +696,7 @@ int crt_render_rows_ex(const crt_scene* scene, const crt_camera* camera, crt_rng
 
 int crt_scene_set_materials(crt_scene* s, const crt_material* table, int n_materials, const int* triangle_material) {
     if (!s || !table || n_materials < 1) return fail(CRT_ERR_INVALID, "crt_scene_set_materials: null or empty table");
+    if (n_materials > 65536) return fail(CRT_ERR_UNSUPPORTED, "crt_scene_set_materials: %d materials (the kernels keep 16-bit material indices)", n_materials);
     for (int k = 0; k < n_materials; ++k)
         if (table[k].kind < CRT_LAMBERTIAN || table[k].kind > CRT_DIFFUSE_LIGHT)
             return fail(CRT_ERR_INVALID, "crt_scene_set_materials: material %d has kind %d", k, table[k].kind);

@@ -166,10 +166,17 @@ __device__ __forceinline__ V3 sky_of(V3 d) {   // backgroundSky(d), render.h:41-
 
 // shader: 0 LambertShade, 1 shade, 2 shade_normal.  256 threads = four 8x8 pixel tiles.
 template <bool FAST, bool BVH>
+#ifndef CRT_GENERIC_OCC
+#define CRT_GENERIC_OCC 0   // 0: no occupancy target beyond the block size
+#endif
+#if CRT_GENERIC_OCC
+__global__ void __launch_bounds__(256, CRT_GENERIC_OCC)
+#else
 __global__ void __launch_bounds__(256)
+#endif
 render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __restrict__ state, float* __restrict__ rgb,
                       int shader, int max_depth, int force_mode) {
-    __shared__ int level_mat[kMaxDepthLevels][256];
+    __shared__ unsigned short level_mat[kMaxDepthLevels][256];   // material indices (crt_scene_set_materials: at most 65 536 materials)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int xr = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -214,7 +221,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
                 const MaterialPOD m = sc.materials[mi];
                 V3 att, s_o, s_d;
                 if (depth > 0 && scatter_dev(m, r_d, rec, att, s_o, s_d, rs)) {   // render.h:58
-                    level_mat[levels][threadIdx.x] = mi;
+                    level_mat[levels][threadIdx.x] = (unsigned short)mi;
                     ++levels;
                     r_o = s_o;
                     r_d = s_d;
