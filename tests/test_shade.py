@@ -181,3 +181,35 @@ def test_gpu_lambert_entry_points_follow_the_material_table(gpu, oracle):
         api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, shader=api.SHADER_SHADE, max_depth=40)
     with pytest.raises(_lib.CrtError):
         scene.set_materials([(9, (0, 0, 0), 0.0)])
+
+
+@pytest.mark.gpu
+def test_gpu_shade_on_the_c3_mesh_matches_oracle_crops(gpu, oracle, tmp_path):
+    """The generic kernel at the size the benchmarks use: BASELINE configs[2]'s mesh (100 000 triangles, OBJ round
+    trip, reference camera), BVH world, all four material classes dealt over the triangles, recursive shade with
+    depth 8 at 1920x1080 — crops on the silhouette and in the interior against the oracle, bit for bit."""
+    path, nx, ny, _ = scenes.baseline_obj("C3", str(tmp_path))
+    spp = 2
+    mats = [(api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0), (api.METAL, (0.8, 0.85, 0.88), 0.1), (api.DIELECTRIC, (1.0, 1.0, 1.0), 1.5),
+            (api.DIFFUSE_LIGHT, (4.0, 4.0, 4.0), 0.0)]
+    scene = api.Scene.from_obj(path, scale=1.0)
+    of = (np.arange(scene.n_triangles) % 4).astype(np.int32)
+    cam = api.init_camera(nx, ny)
+    st = api.SetCurandState(nx, ny, 0)
+    api.create_BVHfromList(scene, st)
+    scene.set_materials(mats, of)
+    got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH, api.SHADER_SHADE, 8)
+    lam = (got[..., 0] - got[..., 2]) > 0.05                                   # something that is not sky
+    rows_hit = np.where(lam.any(axis=1))[0]
+    r_mid = int((rows_hit[0] + rows_hit[-1]) // 2)
+    c_edge = int(np.where(lam[r_mid])[0][0])
+    pts, idx = oracle.parse_obj(path)
+    w = oracle.World(pts, idx, None, 1)
+    w.set_materials(mats, of)
+    ocam = oracle.make_camera((0, 100, 1000), (0, 150, 0), (0, 1, 0), 40.0, np.float32(nx) / np.float32(ny), 0.0, 10.0)
+    for win in [(r_mid, r_mid + 12, c_edge - 24, c_edge + 24), (r_mid + 40, r_mid + 48, nx // 2 - 16, nx // 2 + 16)]:
+        states = oracle.fresh_states(nx, ny, window=win)
+        bvh = oracle.Bvh(w, states)
+        ref, _ = oracle.render_ex(w, bvh, oracle.SHADER_SHADE, ocam, nx, ny, spp, states, window=win, max_depth=8)
+        r0, r1, c0, c1 = win
+        assert same(got[r0:r1, c0:c1], ref[r0:r1, c0:c1]), win
