@@ -213,3 +213,41 @@ def test_gpu_shade_on_the_c3_mesh_matches_oracle_crops(gpu, oracle, tmp_path):
         ref, _ = oracle.render_ex(w, bvh, oracle.SHADER_SHADE, ocam, nx, ny, spp, states, window=win, max_depth=8)
         r0, r1, c0, c1 = win
         assert same(got[r0:r1, c0:c1], ref[r0:r1, c0:c1]), win
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(4))
+def test_gpu_shade_random_soups_match_oracle(gpu, oracle, block):
+    """Randomised: small soups (triangles in front of, around and behind the eye, coincident duplicates, degenerate
+    ones), random material tables and assignments, both worlds, random depth and shader — pixels (NaNs included) and
+    RNG states against the oracle."""
+    for seed in range(1000 + 12 * block, 1000 + 12 * (block + 1)):
+        rng = np.random.RandomState(seed)
+        n = int(rng.choice([3, 17, 64, 150]))
+        sc = scenes.random_soup(n, seed, extent=float(rng.choice([2.0, 4.0])), size=float(rng.choice([0.7, 1.5, 3.0])))
+        kinds = [api.LAMBERTIAN, api.METAL, api.DIELECTRIC, api.DIFFUSE_LIGHT]
+        mats = [(int(rng.choice(kinds)), tuple(float(x) for x in rng.uniform(0.05, 1.0, 3)), float(rng.choice([0.0, 0.3, 1.5, 2.4])))
+                for _ in range(int(rng.randint(1, 7)))]
+        of = rng.randint(0, len(mats), n).astype(np.int32)
+        nx, ny, spp = int(rng.choice([16, 33])), int(rng.choice([8, 20])), int(rng.choice([1, 2, 3]))
+        world = str(rng.choice(["list", "bvh"]))
+        shader = int(rng.choice([api.SHADER_SHADE, api.SHADER_SHADE, api.SHADER_LAMBERT, api.SHADER_NORMAL]))
+        depth = int(rng.choice([0, 1, 2, 8, 31]))
+        w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        w.set_materials(mats, of)
+        c = sc["camera"]
+        ocam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
+        scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+        st = api.SetCurandState(nx, ny, 0)
+        states = oracle.fresh_states(nx, ny)
+        bvh = None
+        if world == "bvh":
+            api.create_BVHfromList(scene, st)
+            bvh = oracle.Bvh(w, states)
+        scene.set_materials(mats, of)
+        ref, states = oracle.render_ex(w, bvh, shader, ocam, nx, ny, spp, states, max_depth=depth)
+        after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+        got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH if world == "bvh" else api.WORLD_LIST, shader, depth)
+        assert same(got, ref), (seed, world, shader, depth, n)
+        assert np.array_equal(st.export()[1:], after[1:]), (seed, world, shader, depth, n)
