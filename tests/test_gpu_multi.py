@@ -215,3 +215,29 @@ def test_bench_under_torchrun_two_ranks_sharing_the_gpu(gpu):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
     assert "strips" in out["config"]["parallelism"]
+
+
+def test_bench_line_carries_the_contract_fields(gpu):
+    """python bench.py (the driver's N=1 command, here with few steps and samples): ONE JSON line with the contract's
+    fields, the roofline and cpu_baseline objects, and the oracle crop of the timed frame bit-identical."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--spp", "2", "--no-extras"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["unit"] == "Mrays/s" and out["dtype"] == "f32"
+    assert out["vs_baseline"] is None and out["higher_is_better"] is True and out["data"] == "synthetic" and "workload" in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
+    assert out["parity_crop"] is True and out["parity_crop_hit_pixels"] > 0
