@@ -108,6 +108,7 @@ PROTOTYPES = {
     "crt_multi_device_count": (C.c_int, [C.c_void_p]),
     "crt_multi_free": (None, [C.c_void_p]),
     "crt_write_png_rgba8": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
+    "crt_encode_png_rgba8": (C.c_longlong, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_longlong]),
     "crt_to_rgba8": (None, [_fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "crt_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _fp]),
 }

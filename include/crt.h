@@ -393,11 +393,16 @@ void crt_multi_free(crt_multi *m);
 void crt_to_rgba8(const float *rgb, int nx, int ny, unsigned char *rgba);
 
 /* replaces: WritePng (core/render.h:135-157): the conversion above, then an RGBA8 PNG at
- * `path` (the reference calls stbi_write_png(path, nx, ny, 4, rgb, 0), :153; this library
- * carries its own zlib-based PNG encoder — same pixels, not the same compressed bytes). */
+ * `path`.  The reference calls stbi_write_png(path, nx, ny, 4, rgb, 0) (:153) of the
+ * stb_image_write.h it vendors; this library restates that encoder's procedure (row filter
+ * choice, its LZ77 matcher, fixed Huffman codes: csrc/crt_png.cpp) and writes the SAME FILE,
+ * byte for byte — pinned against the reference's encoder itself (tests/test_png.py). */
 int crt_write_png(const char *path, int nx, int ny, const float *rgb);
 /* The encoder alone: rgba is nx*ny*4 bytes, top row first (what crt_to_rgba8 produces). */
 int crt_write_png_rgba8(const char *path, int nx, int ny, const unsigned char *rgba);
+/* The same file in memory: returns its length in bytes (negative: error) and copies it to `out`
+ * when it fits `capacity` (out may be NULL to ask for the length). */
+long long crt_encode_png_rgba8(const unsigned char *rgba, int nx, int ny, unsigned char *out, long long capacity);
 
 #ifdef __cplusplus
 }

@@ -114,10 +114,30 @@ def decode_png(path):
         pos += 12 + n
     nx, ny, depth, ctype = hdr[:4]
     assert depth == 8 and ctype == 6
-    raw = zlib.decompress(idat)
+    raw = zlib.decompress(idat)                                    # an independent inflater (python's zlib)
     rows = np.frombuffer(raw, dtype=np.uint8).reshape(ny, nx * 4 + 1)
-    assert (rows[:, 0] == 0).all()
-    return rows[:, 1:].reshape(ny, nx, 4)
+    out = np.zeros((ny, nx * 4), dtype=np.int64)
+    for y in range(ny):                                            # undo the row filters (PNG spec 9.2)
+        f, line = int(rows[y, 0]), rows[y, 1:].astype(np.int64)
+        up = out[y - 1] if y else np.zeros(nx * 4, dtype=np.int64)
+        assert 0 <= f <= 4
+        if f == 0:
+            out[y] = line
+        elif f == 2:
+            out[y] = (line + up) & 255
+        else:
+            for i in range(nx * 4):
+                a = out[y, i - 4] if i >= 4 else 0
+                b, c = up[i], (up[i - 4] if i >= 4 else 0)
+                if f == 1:
+                    pred = a
+                elif f == 3:
+                    pred = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                out[y, i] = (line[i] + pred) & 255
+    return out.astype(np.uint8).reshape(ny, nx, 4)
 
 
 def test_rgba8_and_png_match_oracle(crt_built, oracle, golden_dir, tmp_path):
