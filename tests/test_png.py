@@ -87,3 +87,24 @@ def test_png_decodes_to_its_pixels(crt_built, tmp_path):
         h, w, _ = img.shape
         assert crt_built.crt_write_png_rgba8(path.encode(), w, h, np.ascontiguousarray(img).ctypes.data_as(C.POINTER(C.c_ubyte))) == 0
         assert np.array_equal(decode_png(path), img), name
+
+
+def test_timing_csv_equals_the_reference_writer(crt_built, tmp_path):
+    """output.csv (kernel.cu:61,101): crt_write_timing_csv against the reference's own writeCSV (Loader/CSVWriter.h, built from
+    the reference's file into oracle/_ref/libref_csv.so) fed the rows its call sites build."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "oracle", "_ref", "libref_csv.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_csv.so not built (no reference tree on this machine)")
+    ref = C.CDLL(path)
+    ref.ref_write_csv.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
+    rng = np.random.RandomState(11)
+    for n in (0, 1, 7):
+        frames = (C.c_int * max(n, 1))(*range(3, 3 + max(n, 1)))
+        rend = (C.c_double * max(n, 1))(*[float(x) for x in rng.uniform(0.0, 40.0, max(n, 1))])
+        upd = (C.c_double * max(n, 1))(*[float(x) for x in 10.0 ** rng.uniform(-7, 3, max(n, 1))])
+        build = float(rng.uniform(0, 2))
+        a, b = str(tmp_path / ("ref%d.csv" % n)), str(tmp_path / ("crt%d.csv" % n))
+        assert ref.ref_write_csv(a.encode(), n, frames, rend, upd, build) == 0
+        assert crt_built.crt_write_timing_csv(b.encode(), n, frames, rend, upd, C.c_double(build)) == 0
+        assert open(a, "rb").read() == open(b, "rb").read(), n
