@@ -61,6 +61,16 @@ def test_png_bytes_equal_the_reference_encoder(crt_built):
             img = rng.randint(0, 256, (h, w, 4))
         img = (np.asarray(img) % 256).astype(np.uint8)
         assert np.array_equal(product_encode(crt_built, img), ref(img)), (seed, kind, h, w)
+    # one frame of the benchmark's size: sky gradient, a noisy red disc (8.3 MB of filtered rows, many window wrap-arounds)
+    h, w = 1080, 1920
+    yy, xx = np.mgrid[0:h, 0:w]
+    t = yy / (h - 1)
+    rng = np.random.RandomState(1)
+    sky = np.stack([255 * (1 - 0.5 * t), 255 * (1 - 0.3 * t), 255 + 0 * t, 255 + 0 * t], -1)
+    disc = ((xx - w / 2) ** 2 + (yy - h / 2) ** 2) < 300 ** 2
+    red = np.stack([150 + rng.randint(0, 40, (h, w)), 10 + rng.randint(0, 8, (h, w)), 10 + rng.randint(0, 8, (h, w)), 255 + 0 * xx], -1)
+    img = np.where(disc[..., None], red, sky).astype(np.uint8)
+    assert np.array_equal(product_encode(crt_built, img), ref(img))
 
 
 def test_write_png_is_the_reference_pipeline(crt_built, oracle, tmp_path):
