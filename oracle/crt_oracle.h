@@ -14,6 +14,10 @@
  * reference file:line it follows, paths relative to /root/reference/CudaTest/src) and
  * of cuRAND's published XORWOW algorithm (CUDA Toolkit 12.2 curand_kernel.h, not in the
  * reference tree).  It defines "the reference on the host CPU" for this repository.
+ * (Two pieces of the reference ARE plain C/C++ and build from their own files, into
+ * oracle/_ref/ — `make ref`: the PNG encoder WritePng calls, ref_stb_png.c, and the
+ * timing table's writer, ref_csv.cpp.  They pin the product's output files byte for byte,
+ * tests/test_png.py; they say nothing about the render path.)
  *
  * Floating point: every operation is IEEE-754 binary32 evaluated in source order with
  * no contraction (build with -ffp-contract=off), except the reference's double-typed
