@@ -168,7 +168,7 @@ class World:
         self.points = pts
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:   # (module globals are gone at interpreter shutdown)
             lib().o_world_free(self.handle)
             self.handle = None
 
@@ -213,7 +213,7 @@ class Bvh:
         return bool(flag), np.float32(t.value), idx.value, np.array(list(nrm), dtype=np.float32)
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:
             lib().o_bvh_free(self.handle)
             self.handle = None
 
