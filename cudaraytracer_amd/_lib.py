@@ -95,6 +95,7 @@ PROTOTYPES = {
     "crt_debug_check_division": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
     "crt_debug_audit_tiles": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_int, C.c_int, C.c_int, C.c_uint64,
                                         C.POINTER(C.c_uint64)]),
+    "crt_debug_vec3": (C.c_int, [C.c_int, C.c_int, C.c_longlong, _fp, _fp, _fp, _fp]),
     "crt_last_kernel_ms": (C.c_float, []),
     "crt_last_kernel_times": (C.c_int, [C.POINTER(C.c_float)]),
     "crt_strip_part_stride": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1013,6 +1013,46 @@ int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t* mismatc
     return CRT_OK;
 }
 
+int crt_debug_vec3(int where, int op, long long n, const float* a, const float* b, const float* s, float* out) {
+    if (n < 0 || (n > 0 && (!a || !b || !s || !out))) return fail(CRT_ERR_INVALID, "crt_debug_vec3: null array");
+    if (where == 0) {   // the host helpers of crt_internal.hpp (camera constructor, scene pack, BVH build)
+        for (long long i = 0; i < n; ++i) {
+            const H3 A = h3(a + 3 * i), B = h3(b + 3 * i);
+            H3 R{0.0f, 0.0f, 0.0f};
+            switch (op) {
+                case 1: R = hsub(A, B); break;
+                case 3: R = hmul(s[i], A); break;
+                case 7: R = hcross(A, B); break;
+                case 10: R = hunit(A); break;
+                case 14: R = hrotate(A, B); break;
+                default: return fail(CRT_ERR_UNSUPPORTED, "crt_debug_vec3: the host layer has no helper for op %d", op);
+            }
+            out[3 * i] = R.x; out[3 * i + 1] = R.y; out[3 * i + 2] = R.z;
+        }
+        return CRT_OK;
+    }
+    if (where != 1) return fail(CRT_ERR_INVALID, "crt_debug_vec3: where must be 0 (host helpers) or 1 (device functions)");
+    switch (op) {
+        case 1: case 3: case 6: case 7: case 8: case 10: case 11: case 12: case 13: case 100: case 101: case 102: break;
+        default: return fail(CRT_ERR_UNSUPPORTED, "crt_debug_vec3: the kernels have no device function for op %d", op);
+    }
+    if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_debug_vec3: no HIP device");
+    if (n == 0) return CRT_OK;
+    float* d = nullptr;
+    const size_t n3 = (size_t)n * 3;
+    HIP_TRY(hipMalloc(&d, (3 * n3 + (size_t)n) * sizeof(float)));
+    float *d_a = d, *d_b = d + n3, *d_out = d + 2 * n3, *d_s = d + 3 * n3;
+    hipError_t e = hipMemcpy(d_a, a, n3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_b, b, n3 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_s, s, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = crt::launch_vec3_ops(op, n, d_a, d_b, d_s, d_out, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, n3 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CRT_ERR_HIP, "crt_debug_vec3: %s", hipGetErrorString(e));
+    return CRT_OK;
+}
+
 int crt_last_kernel_times(float* ms3) {
     // ms3[0] = all render kernels of the last crt_render_rows of this thread, ms3[1] = prepasses +
     // binning, ms3[2] = shading kernel (tiled variant) or the brute-force kernel; HIP events on the

@@ -146,6 +146,7 @@ hipError_t launch_audit(const RenderParams& p, const float* d_rec, const float4*
                         hipStream_t stream);
 hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, unsigned long long* d_bad,
                                    hipStream_t stream);
+hipError_t launch_vec3_ops(int op, long long n, const float* d_a, const float* d_b, const float* d_s, float* d_out, hipStream_t stream);
 constexpr int kStatsWords = 48;
 constexpr int kStatsTimeline = 47;   // != 0: shade_tiles_kernel records only its timeline (below), at full speed
 constexpr int kStatsWaveSlots = 8192;                 // timeline: per wave (block * waves + wave) four words, three 100 MHz time stamps:

@@ -2627,6 +2627,54 @@ hipError_t launch_check_reciprocal(int mode, uint32_t exp_lo, uint32_t exp_hi, u
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ vec3 arithmetic, one operation at a time
+// crt_debug_vec3 (where = 1): the device functions the kernels above are built from, applied to arrays, so that
+// tests/test_vec3_ref.py can hold them to vectors the reference's own core/vec3.h produced on the host
+// (tests/golden/vec3_ref_vectors.npz).  Op codes of oracle/ref_vec3.cpp; 100.. are this file's fast forms, which must
+// give the bits of the plain ones.
+__global__ void __launch_bounds__(64)
+vec3_ops_kernel(int op, long long n, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ s,
+                float* __restrict__ out) {
+    const long long i0 = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long i = i0 < n ? i0 : n - 1;            // every lane computes (the fast forms vote across the wavefront)
+    const V3 A{a[3 * i], a[3 * i + 1], a[3 * i + 2]}, B{b[3 * i], b[3 * i + 1], b[3 * i + 2]};
+    const float t = s[i];
+    V3 R{0.0f, 0.0f, 0.0f};
+    switch (op) {
+        case 1: R = V3{A.x - B.x, A.y - B.y, A.z - B.z}; break;                       // derive_record: e1, e2, s (vec3.h:77-79)
+        case 3: R = V3{t * A.x, t * A.y, t * A.z}; break;                             // vec3.h:93-99
+        case 6: R.x = A.x * B.x + A.y * B.y + A.z * B.z; break;                       // dot as the exact tests spell it (vec3.h:109-111)
+        case 7: R = V3{(A.y * B.z - A.z * B.y), (-(A.x * B.z - A.z * B.x)), (A.x * B.y - A.y * B.x)}; break;   // vec3.h:113-117
+        case 8: R.x = sqrtf(A.x * A.x + A.y * A.y + A.z * A.z); break;                // vec3.h:38-40
+        case 10: R = unit_vector(A); break;                                           // vec3.h:191-193
+        case 11: {                                                                    // backgroundSky's lerp (render.h:45) = sky_from_unit:
+            R = sky_from_unit(V3{0.0f, 2.0f * t - 1.0f, 0.0f});                       //   t = 0.5f * (y + 1.0f) with y = 2t - 1 exact for the t used
+            break;
+        }
+        case 12:                                                                      // clip, vec3.h:119-131, as render_pixel spells it
+            R.x = (A.x > 1.0f) ? 1.0f : ((A.x < 0.0f) ? 0.0f : A.x);
+            R.y = (A.y > 1.0f) ? 1.0f : ((A.y < 0.0f) ? 0.0f : A.y);
+            R.z = (A.z > 1.0f) ? 1.0f : ((A.z < 0.0f) ? 0.0f : A.z);
+            break;
+        case 13: {                                                                    // col /= float(ns), vec3.h:182-189, as render_pixel spells it
+            const float k = (float)(1.0 / (double)t);
+            R = V3{A.x * k, A.y * k, A.z * k};
+            break;
+        }
+        case 100: R = unit_vector_fast(A); break;                                     // == op 10
+        case 101: R.y = unit_vector_fast_y(A); break;                                 // == op 10's y
+        case 102: R = sky_from_unit(A); break;                                        // lerp(0.5f * (A.y + 1.0f), vec3(1), vec3(0.5, 0.7, 1.0))
+        default: break;
+    }
+    if (i0 < n) { out[3 * i] = R.x; out[3 * i + 1] = R.y; out[3 * i + 2] = R.z; }
+}
+
+hipError_t launch_vec3_ops(int op, long long n, const float* d_a, const float* d_b, const float* d_s, float* d_out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(vec3_ops_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, op, n, d_a, d_b, d_s, d_out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ multi-GPU reassembly
 // Rank 0 after the gather: rank r's piece (its 32-row strips one after the other) starts at
 // parts + r * part_stride; global strip s belongs to rank s % world and is that rank's strip

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 2
+#define CRT_ABI_VERSION 3
 
 enum {
     CRT_OK = 0,
@@ -322,6 +322,14 @@ int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t *mismatches);
  * square root of normal floats (v_sqrt_f32 + neighbour residuals) against sqrtf for every positive
  * float with biased exponent in [exp_lo, exp_hi]. */
 int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t *mismatches);
+
+/* One core/vec3.h operation at a time on arrays (a, b, out: n x 3 floats, s: n floats; host pointers): where = 0 the
+ * host layer's helpers (camera constructor, scene pack, BVH build: ops 1 sub, 3 s*a, 7 cross, 10 unit_vector,
+ * 14 rotate), where = 1 the kernels' device functions (ops 1, 3, 6 dot, 7, 8 length, 10, 11 sky lerp of t = s,
+ * 12 clip, 13 a /= s, and the fast forms 100 unit_vector_fast, 101 its y alone, 102 sky_from_unit).  Op codes are
+ * those of oracle/ref_vec3.cpp, which wraps the reference's own core/vec3.h (replaces: core/vec3.h:73-217);
+ * tests/test_vec3_ref.py compares bit for bit.  CRT_ERR_UNSUPPORTED for an operation that side does not have. */
+int crt_debug_vec3(int where, int op, long long n, const float *a, const float *b, const float *s, float *out);
 
 /* Duration in milliseconds of the last crt_render_rows main kernel launched through this
  * library on the calling thread, measured with HIP events on the launch stream.

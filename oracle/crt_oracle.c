@@ -80,6 +80,38 @@ static o_vec3 rotate(o_vec3 origin, o_vec3 rotation) {                          
     return v3(sum3(mulv(origin, rotate0)), sum3(mulv(origin, rotate1)), sum3(mulv(origin, rotate2)));
 }
 
+/* The vec3 restatements above, one operation at a time, for tests/test_vec3_ref.py: held bit for bit to the reference's
+ * own core/vec3.h compiled for the host (oracle/ref_vec3.cpp -> oracle/_ref/libref_vec3.so).  Same op codes, same
+ * layout: a, b, out are n x 3 floats, s is n floats; scalar results go to out[3i].  Returns 1 for an operation the
+ * oracle does not restate (nothing on the path uses it). */
+int o_vec3_op(int op, long long n, const float *a, const float *b, const float *s, float *out) {
+    for (long long i = 0; i < n; i++) {
+        o_vec3 A = v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]), B = v3(b[3 * i], b[3 * i + 1], b[3 * i + 2]), R = v3(0, 0, 0);
+        float t = s[i];
+        switch (op) {
+            case 0: R = add(A, B); break;
+            case 1: R = sub(A, B); break;
+            case 2: R = mulv(A, B); break;
+            case 3: R = muls(t, A); break;
+            case 4: R = divv(A, B); break;
+            case 5: R = divs(A, t); break;
+            case 6: R = v3(dot(A, B), 0, 0); break;
+            case 7: R = cross(A, B); break;
+            case 8: R = v3(length(A), 0, 0); break;
+            case 9: R = v3(squared_length(A), 0, 0); break;
+            case 10: R = unit_vector(A); break;
+            case 11: R = lerp3(t, A, B); break;
+            case 12: R = clip(A); break;
+            case 13: R = div_assign_s(A, t); break;
+            case 14: R = rotate(A, B); break;
+            case 17: R = v3(sum3(A), 0, 0); break;
+            default: return 1;
+        }
+        out[3 * i] = R.e[0]; out[3 * i + 1] = R.e[1]; out[3 * i + 2] = R.e[2];
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ core/ray.h */
 
 typedef struct { float _time; o_vec3 _origin; o_vec3 _direction; } o_ray;                              /* ray.h:20-22 */

@@ -180,6 +180,10 @@ int o_world_hit(const o_world *world, const float origin[3], const float directi
  * char(255.99*c). rgba: nx*ny*4 bytes. */
 void o_to_rgba8(const float *colorBuffer, int nx, int ny, unsigned char *rgba);
 
+/* ---- one core/vec3.h operation at a time (op codes of oracle/ref_vec3.cpp); pinned against the reference's own
+ * vec3.h by tests/test_vec3_ref.py.  Returns 1 for an operation the oracle does not restate. */
+int o_vec3_op(int op, long long n, const float *a, const float *b, const float *s, float *out);
+
 #ifdef __cplusplus
 }
 #endif

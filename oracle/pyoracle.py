@@ -75,6 +75,8 @@ def lib():
         L.o_world_hit.argtypes = [C.c_void_p, fp, fp, fp, C.POINTER(C.c_int), fp]
         L.o_world_hit.restype = C.c_int
         L.o_to_rgba8.argtypes = [fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
+        L.o_vec3_op.argtypes = [C.c_int, C.c_longlong, fp, fp, fp, fp]
+        L.o_vec3_op.restype = C.c_int
         L.o_bvh_build.argtypes = [C.c_void_p, C.c_void_p]
         L.o_bvh_build.restype = C.c_void_p
         L.o_bvh_update.argtypes = [C.c_void_p]
@@ -291,3 +293,14 @@ def to_rgba8(buf):
     b = np.ascontiguousarray(buf, dtype=np.float32)
     lib().o_to_rgba8(_fp(b), nx, ny, out.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return out
+
+
+def vec3_op(op, a, b, s):
+    """o_vec3_op: one core/vec3.h operation on arrays (op codes of oracle/ref_vec3.cpp); None if the oracle does not
+    restate that operation."""
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3)
+    b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1, 3)
+    s = np.ascontiguousarray(s, dtype=np.float32).reshape(-1)
+    out = np.zeros_like(a)
+    rc = lib().o_vec3_op(int(op), len(a), _fp(a), _fp(b), _fp(s), _fp(out))
+    return out if rc == 0 else None

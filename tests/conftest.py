@@ -38,15 +38,13 @@ def crt_built():
 
 @pytest.fixture(scope="session")
 def gpu(crt_built):
-    """torch with a usable HIP device (GPU tests only).  Fails — never skips — without one: the
-    product has no CPU fallback.  A fresh box can take a moment to expose the device to torch."""
+    """torch with a usable HIP device (GPU tests only).  Fails at once — never skips, never waits — without one: the
+    product has no CPU fallback."""
     if crt_built.crt_device_count() < 1:
         pytest.fail("no HIP device visible: the product has no CPU fallback")
-    import time
     import torch
-    for _ in range(10):
-        if torch.cuda.is_available():
-            break
-        time.sleep(2.0)
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        pytest.fail("torch sees no device although libcrt_hip.so does: two HIP runtimes in this process — something loaded "
+                    "libamdhip64.so.7 before torch did (import torch before libcrt_hip.so or any other ROCm library; "
+                    "cudaraytracer_amd/_lib.py, INTEGRATION.md \"One HIP runtime per process\")")
     return torch

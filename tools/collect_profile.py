@@ -24,7 +24,7 @@ for r in csv.DictReader(open(stats[0])):
 for key, name in (("shade_tiles_kernel", "shade"), ("bin_tri_kernel", "bin_walk"), ("cls_prepass_kernel", "prepass")):
     match = [k for k in avg if key in k]
     if match:
-        subprocess.call([sys.executable, os.path.join(root, "tools", "summarise_pmc.py"), prof, key, repr(avg[match[0]]),
+        subprocess.call([sys.executable, os.path.join(root, "tools", "summarise_pmc.py"), prof, key,
                          os.path.join(out, "pmc_summary_%s.json" % name)])
 for f in ("bench_trace.json",):
     if os.path.exists(os.path.join(prof, f)):
