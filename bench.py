@@ -69,8 +69,31 @@ def algorithmic_bytes_tiled(nx, rows, spp, n_tris, base_bytes, sum2):
     return bin_b, shade_b
 
 
-def cpu_baseline(obj_path, budget_rays=1536):
-    """Oracle (serial CPU port of the reference loop) on a centred crop of the same frame."""
+def host_cpu():
+    """Model string and usable core count of this host (state the core model and count)."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return model, n
+
+
+CPU_SHARE = 16      # a one-GPU box of this pool gives a job 16 of the host's cores, whatever the affinity mask shows
+
+
+def cpu_baseline(obj_path, reps=3):
+    """Oracle (serial CPU port of the reference loop) on a crop of the same frame, SURVEY §8d's protocol: the
+    single-thread figure (= the reference's serial loop; median of `reps` repetitions) and, labelled as such, an
+    all-cores figure (the crop's rows dealt to one thread per usable core; ctypes releases the GIL)."""
+    import threading
     from oracle import pyoracle as po
     pts, idx = po.parse_obj(obj_path)
     w = po.World(pts, idx, None, 1)
@@ -80,21 +103,43 @@ def cpu_baseline(obj_path, budget_rays=1536):
     r0, c0 = 500, NX // 2 - 250             # on the mesh, near its left silhouette (the mesh covers rows ~20..620)
     win = (r0, r0 + ch, c0, c0 + cw)
     po.render(w, cam, NX, NY, 1, window=(r0, r0 + 1, c0, c0 + 2))      # warm caches / tables
-    import ctypes as C
-    states = np.zeros(NX * NY, dtype=po.STATE_DTYPE)
-    L = po.lib()
-    L.o_set_curand_state_range(states.ctypes.data, 0, 1, 0)
-    for y in range(r0, r0 + ch):
-        first = y * NX + c0
-        L.o_set_curand_state_range(states[first:].ctypes.data, first, cw, 0)
-    t0 = time.perf_counter()
-    ref, _ = po.render(w, cam, NX, NY, cs, window=win, states=states)
-    dt = time.perf_counter() - t0
+    model, n_visible = host_cpu()
+    n_cores = min(n_visible, CPU_SHARE)
+    times, ref = [], None
+    for _ in range(reps):
+        states = po.fresh_states(NX, NY, window=win)                   # outside the timed part, like the GPU's SetCurandState
+        t0 = time.perf_counter()
+        ref, _ = po.render(w, cam, NX, NY, cs, window=win, states=states)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     rays = cw * ch * cs
+    # all cores: 4 rows of the same 32-pixel-wide window per thread, every thread with its own state array (get_ray
+    # draws its lens sample from stream 0 for every pixel, core/render.h:118 — private copies keep the threads apart;
+    # untouched pages of the zero-filled arrays are never committed)
+    rows_per = 4
+    wins = [(r0 + rows_per * k, r0 + rows_per * (k + 1), c0, c0 + cw) for k in range(n_cores)]
+    all_times = []
+    for _ in range(reps):
+        sts = [po.fresh_states(NX, NY, window=wk) for wk in wins]
+        ths = [threading.Thread(target=po.render, args=(w, cam, NX, NY, cs), kwargs={"window": wk, "states": sk}) for wk, sk in zip(wins, sts)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        all_times.append(time.perf_counter() - t0)
+    dt_all = float(np.median(all_times))
+    rays_all = cw * rows_per * cs * n_cores
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "cpu_model": model, "host_cores_visible": n_visible, "host_cores": n_cores, "repetitions": reps, "seconds": [round(x, 3) for x in times],
             "sample": "oracle/crt_oracle.c (gcc -O2, 1 thread), %dx%d px crop (rows %d.., columns %d.., on the mesh) x %d spp "
-                      "of the 1920x1080 frame against all %d triangles: %d rays in %.1f s"
-                      % (cw, ch, r0, c0, cs, w.n_tris, rays, dt)}, win, cs, ref[r0:r0 + ch, c0:c0 + cw]
+                      "of the 1920x1080 frame against all %d triangles: %d rays, median of %d repetitions %.1f s"
+                      % (cw, ch, r0, c0, cs, w.n_tris, rays, reps, dt),
+            "all_cores": {"value": rays_all / dt_all / 1e6, "unit": "Mrays/s", "cores": n_cores,
+                          "seconds": [round(x, 3) for x in all_times],
+                          "sample": "the same oracle, %d threads (the job's CPU share: min(visible cores, 16)) x %d rows of the same %d-pixel-wide window "
+                                    "x %d spp: %d rays, median of %d repetitions %.1f s (row-parallel; NOT the reference's serial loop)"
+                                    % (n_cores, rows_per, cw, cs, rays_all, reps, dt_all)}}, win, cs, ref[r0:r0 + ch, c0:c0 + cw]
 
 
 def hip_crop(scene, camera, win, spp):
@@ -247,7 +292,22 @@ def main():
         torch.cuda.synchronize()
         ms_b = (time.perf_counter() - t1) / 10 * 1e3
         bvh_world = {"what": "same frame, world = BVHNode tree (crt_render_rows_bvh): tiled kernels + chain of boxes per winner",
+                     "parity": "PARITY UNPINNED: checked against the in-repo oracle only; the tree's shape rests on a reading of "
+                               "thrust::sort's sequential merge sort under a non-strict comparator (hitable/bvh.h:9-45,86-92)",
                      "ms_per_frame": ms_b, "Mrays/s": NX * NY * args.spp / ms_b / 1e3, "host_build_s": build_s}
+
+    # The one-call surface crt_render(width, height, samples, list, camera) -> HOST RGB buffer: states restored from
+    # the seed, the frame, 24.9 MB over PCIe into a pageable buffer.  Reported beside the resident figure, never as it.
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        api.render(NX, NY, args.spp, scene, camera, seed=0)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            api.render(NX, NY, args.spp, scene, camera, seed=0)
+        ms_p = (time.perf_counter() - t1) / 5 * 1e3
+        pcie = {"what": "crt_render: RNG states restored for the seed + the frame + D2H copy of the 24.9 MB float3 frame into a pageable "
+                        "host buffer, per call (host wall clock, 5 calls)", "ms_per_call": ms_p, "Mrays/s": NX * NY * args.spp / ms_p / 1e3}
+        api.stream_release(None)
 
     if rank == 0:
         rays = NX * NY * args.spp * args.steps
@@ -278,7 +338,7 @@ def main():
         # committed rocprofv3 PMC passes of this very command (tools/profile_bench.sh; the summary
         # names the commit it was taken at).  The kernel time they are divided by IS this run's.
         traffic, traffic_src, valu = None, None, None
-        for prof in ("r2_tiled", "r1_tiled"):
+        for prof in ("r3_tiled", "r2_tiled", "r1_tiled"):
             pmc = os.path.join(ROOT, "profiles", prof, "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin_walk"))
             if os.path.exists(pmc):
                 break
@@ -292,10 +352,16 @@ def main():
                 # this chip for VGPR-only v_mul/v_add (profiles/r1_ubench_valu2.txt)
                 insts = summary["per_launch_counters"].get("SQ_INSTS_VALU")
                 if insts:
-                    rate = insts / (k_ms * 1e-3) / 1024 / 2.4e9
+                    # the clock the chip ran this kernel at in the PMC pass (same pass: cycles and duration), not the 2.4 GHz
+                    # nominal figure; summaries without it (round 2's) fall back to nominal and say so
+                    ghz = summary["derived"].get("effective_clock_GHz")
+                    clock_src = summary["derived"].get("effective_clock_source")
+                    if not ghz or "same PMC pass" not in (clock_src or ""):
+                        ghz, clock_src = 2.4, "nominal 2.4 GHz (no same-pass clock in the committed summary)"
+                    rate = insts / (k_ms * 1e-3) / 1024 / (ghz * 1e9)
                     valu = {"unit": "wave64 VALU instructions per clock per SIMD", "achieved": rate,
                             "peak": 1 / 2.25, "frac": rate * 2.25, "insts_per_launch": insts,
-                            "source": traffic_src}
+                            "clock_GHz": ghz, "clock_source": clock_src, "source": traffic_src}
             except Exception:
                 traffic = None
         out = {
@@ -318,12 +384,15 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "algorithmic_bytes_per_launch": alg,
+                         "bound_note": "the contract's labels are hbm | mfma; this kernel is neither: the HBM figure is reported "
+                                       "because the metric asks for it, the measured limiter is below",
                          "limiter": "valu issue, not HBM: see valu_issue (DESIGN.md §5)"},
             "valu_issue": valu,
             "kernels": kernels,
             "survivors": survivors,
             "screen_filling_variant": filling,
             "bvh_world": bvh_world,
+            "pcie_inclusive_one_call": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
             base, win, cs, ref = cpu_baseline(obj_path)

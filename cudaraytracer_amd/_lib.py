@@ -87,6 +87,7 @@ PROTOTYPES = {
                                        C.POINTER(C.c_double), C.c_double]),
     "crt_render": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.POINTER(CrtCamera), C.c_uint64, _fp]),
+    "crt_stream_release": (C.c_int, [C.c_void_p]),
     "crt_set_kernel_variant": (C.c_int, [C.c_int]),
     "crt_set_kernel_timing": (C.c_int, [C.c_int]),
     "crt_debug_tiled_stats": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
@@ -102,6 +103,7 @@ PROTOTYPES = {
     "crt_assemble_strips": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "crt_gather_strips": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "crt_debug_inject_send_failure": (C.c_int, [C.c_int]),
     "crt_multi_create": (C.c_void_p, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_uint64, C.c_int]),
     "crt_multi_render": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_int, C.c_int, C.c_int, _fp]),
     "crt_multi_update_pose": (C.c_int, [C.c_void_p, _fp, C.c_int]),

@@ -319,6 +319,12 @@ class MultiRenderer:
             pass
 
 
+def stream_release(stream=None):
+    """crt_stream_release: frees the launch context of `stream` (a torch.cuda.Stream; None = the default stream and what
+    crt_render keeps).  Call before the stream is destroyed."""
+    check(_lib.lib().crt_stream_release(C.c_void_p(stream.cuda_stream) if stream is not None else None))
+
+
 def last_kernel_ms():
     ms = _lib.lib().crt_last_kernel_ms()
     if ms < 0:

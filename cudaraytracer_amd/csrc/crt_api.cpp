@@ -10,6 +10,7 @@
 // point returns CRT_ERR_NO_DEVICE.
 #include "crt_internal.hpp"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -55,19 +56,97 @@ namespace crt_host {
 namespace {
 std::mutex g_ctx_mu;
 std::vector<Context*> g_contexts;
-thread_local Context* g_last_ctx = nullptr;   // crt_last_kernel_ms / crt_last_kernel_times: last launch of this thread
+unsigned long long g_next_ctx_id = 1;
+thread_local unsigned long long g_last_ctx_id = 0;   // crt_last_kernel_ms / crt_last_kernel_times: last launch of this thread
+
+// hipStreamGetId is a hip_7.1 symbol: a process whose HIP runtime is older (PyTorch 2.10's bundled ROCm 7.0 copy) does not
+// have it, so it is looked up at run time; without it every stream reports id 0 and a recycled handle is not noticed
+// (its context is then simply reused, as in round 2).
+unsigned long long stream_id_of(hipStream_t stream) {
+    using Fn = hipError_t (*)(hipStream_t, unsigned long long*);
+    static const Fn fn = reinterpret_cast<Fn>(dlsym(RTLD_DEFAULT, "hipStreamGetId"));
+    unsigned long long id = 0;
+    if (!fn) return 0;
+    if (fn(stream, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return id;
+}
+
+void free_context_memory(Context* c) {   // device memory and events of a context whose stream is idle
+    if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_cls) (void)hipFree(c->d_cls);
+    if (c->w.log) (void)hipFree(c->w.log);
+    if (c->w.pool) (void)hipFree(c->w.pool);
+    if (c->w.tile_desc) (void)hipFree(c->w.tile_desc);
+    if (c->w.queue) (void)hipFree(c->w.queue);
+    if (c->w.tile_count) (void)hipFree(c->w.tile_count);
+    if (c->w.counters) (void)hipFree(c->w.counters);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+}
 }  // namespace
 
 Context* context_for(int device, hipStream_t stream) {
+    const unsigned long long sid = stream_id_of(stream);
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     for (Context* c : g_contexts)
-        if (c->device == device && c->stream == stream) return c;
+        if (c->device == device && c->stream == stream) {
+            if (c->stream_id != sid) {
+                // the handle of a destroyed stream, handed out again: a new stream.  Nothing of the old one may still be
+                // running into the scratch (one device synchronisation, once per recycled handle); time stamps and the
+                // cached occupancy are dropped, the buffers are scratch without state between frames and stay.
+                (void)hipDeviceSynchronize();
+                c->stream_id = sid;
+                c->id = g_next_ctx_id++;
+                c->ev_valid = false;
+                c->ev_has_mid = false;
+                c->cache = crt::LaunchCache{};
+                c->cache_bvh = crt::LaunchCache{};
+            }
+            return c;
+        }
     Context* c = new (std::nothrow) Context;
     if (!c) return nullptr;
+    c->id = g_next_ctx_id++;
     c->device = device;
     c->stream = stream;
+    c->stream_id = sid;
     g_contexts.push_back(c);
     return c;
+}
+
+int release_context(int device, hipStream_t stream) {
+    Context* c = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        for (size_t i = 0; i < g_contexts.size(); ++i)
+            if (g_contexts[i]->device == device && g_contexts[i]->stream == stream) {
+                c = g_contexts[i];
+                g_contexts.erase(g_contexts.begin() + (long)i);
+                break;
+            }
+    }
+    if (!c) return CRT_OK;
+    hipError_t e;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);   // a launch that is being enqueued on this stream finishes enqueueing first
+        e = (c->stream_id == stream_id_of(stream)) ? hipStreamSynchronize(stream) : hipDeviceSynchronize();
+        free_context_memory(c);
+    }
+    delete c;
+    if (e != hipSuccess) return fail(CRT_ERR_HIP, "crt_stream_release: %s", hipGetErrorString(e));
+    return CRT_OK;
+}
+
+// the context crt_last_kernel_* refer to: still alive?  (crt_stream_release may have freed it)
+static Context* last_context_locked_lookup() {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    for (Context* c : g_contexts)
+        if (c->id == g_last_ctx_id) return c;
+    return nullptr;
 }
 
 int ensure_records(Context& cx, int n_tris, int n_pad) {
@@ -87,17 +166,25 @@ int ensure_records(Context& cx, int n_tris, int n_pad) {
     return CRT_OK;
 }
 
-int ensure_workspace(Context& ws, int nx, int rows) {
+int ensure_workspace(Context& ws, int nx, int rows, int n_tris) {
     const int tiles_x = (nx + 7) / 8, tiles_y = (rows + 7) / 8;
     const size_t tiles = (size_t)tiles_x * tiles_y;
-    const size_t want_pool = std::min<size_t>(std::max<size_t>((size_t)16 << 20, tiles * 256), (size_t)1 << 30);
+    // Sized from the frame and the scene (round 2 had floors of 16 M pool entries and 4 M log records = 160 MB per
+    // stream whatever the frame).  The pool holds the tile lists: never more than triangles x tiles entries; 64 per
+    // tile or 8 per triangle is 20x what the bench frames need (C3: sum of lists 104 k for 32 400 tiles).  The log
+    // holds one record per (wavefront of 64 triangles, tile) pair with survivors: never more than wavefronts x tiles.
+    // A frame that overflows either falls back to the whole-list walk for the affected tiles (variants 3 and 8 test
+    // that path): slower, same pixels.
+    const size_t tris = (size_t)std::max(n_tris, 1), waves = (tris + 63) / 64;
+    const size_t want_pool = std::min<size_t>(std::min<size_t>(std::max<size_t>(std::max<size_t>(tiles * 64, tris * 8), (size_t)1 << 18),
+                                                               tris * tiles + 64), (size_t)1 << 30);
     if (!ws.n_cus) HIP_TRY(hipDeviceGetAttribute(&ws.n_cus, hipDeviceAttributeMultiprocessorCount, ws.device));
     if (!ws.w.counters) {
         HIP_TRY(hipMalloc(&ws.w.counters, crt::kCtrWords * sizeof(uint32_t)));
         ws.w.counters64 = reinterpret_cast<unsigned long long*>(ws.w.counters);
     }
-    // the walk's log: one record per (wavefront, tile) pair with survivors — fewer than list entries; same bound
-    const size_t want_log = std::min<size_t>(std::max<size_t>((size_t)4 << 20, tiles * 64), (size_t)1 << 27);
+    const size_t want_log = std::min<size_t>(std::min<size_t>(std::max<size_t>(std::max<size_t>(tiles * 16, waves * 32), (size_t)1 << 16),
+                                                              waves * tiles + 256), (size_t)1 << 27);
     if (want_log > ws.log_entries) {
         if (ws.w.log) (void)hipFree(ws.w.log);
         ws.w.log = nullptr;
@@ -481,11 +568,12 @@ int crt_scene_update_pose(crt_scene* s, const float* new_points, int n_points, v
         return fail(CRT_ERR_INVALID, "crt_scene_update_pose: %d points, the scene was built from %d", n_points, s->n_points);
     if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_scene_update_pose: no HIP device");
     hipStream_t stream = (hipStream_t)stream_;
-    bool finite = true;
+    bool finite = true, tiny = false;
     float max_abs = 0.0f;
     for (size_t k = 0; k < (size_t)n_points * 3; ++k) {
         finite = finite && std::isfinite(new_points[k]);
         max_abs = std::max(max_abs, fabsf(new_points[k]));
+        tiny = tiny || (new_points[k] != 0.0f && fabsf(new_points[k]) < 1.3877787807814457e-17f);   // 2^-56: box_hit_fast's range (crt_bvh.cpp)
     }
     int device = 0;
     HIP_TRY(hipGetDevice(&device));
@@ -509,6 +597,7 @@ int crt_scene_update_pose(crt_scene* s, const float* new_points, int n_points, v
         for (int k = 0; k < 3; ++k)
             memcpy(&s->h_base[(size_t)i * crt::kBaseFloats + 3 * k], new_points + 3 * (size_t)s->h_idx[3 * (size_t)i + (2 - k)], 3 * sizeof(float));
     s->tiled_safe = finite && max_abs <= 274877906944.0f;   // 2^38, as at creation (here over all points)
+    if (s->bvh) s->bvh->coords_not_tiny = !tiny;            // as at the build (there over the triangles' vertices)
     return CRT_OK;
 }
 
@@ -772,7 +861,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     if (!cxp) return fail(CRT_ERR_NOMEM, "crt_render_rows: out of memory");
     Context& cx = *cxp;
     std::lock_guard<std::mutex> lock(cx.mu);
-    g_last_ctx = cxp;
+    g_last_ctx_id = cxp->id;
     {
         int rc = ensure_records(cx, scene->n_tris, scene->n_pad);
         if (rc != CRT_OK) return rc;
@@ -851,7 +940,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         // pixel's winner: shade_tiles_kernel<.., BVH>) whenever the list world's tiled variant is eligible and
         // the fast arithmetic holds; variant 1 (and the test hooks 5, 6) select the per-ray tree walk.
         if (fast && tiled_ok && (g_variant == 0 || g_variant == 2 || g_variant == 7)) {
-            int rc = ensure_workspace(cx, nx, row_count);
+            int rc = ensure_workspace(cx, nx, row_count, scene->n_tris);
             if (rc != CRT_OK) return rc;
             HIP_TRY(crt::launch_frame_prepass(scene->bvh->d_base_slots, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
             HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, 1, &cx.w,
@@ -872,7 +961,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         return CRT_OK;
     }
     if (kernel_variant != 0) {   // one launch: exact + classification records, scratch zeroed
-        int rc = ensure_workspace(cx, nx, row_count);
+        int rc = ensure_workspace(cx, nx, row_count, scene->n_tris);
         if (rc != CRT_OK) return rc;
         HIP_TRY(crt::launch_frame_prepass(scene->d_base, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
     } else {
@@ -920,7 +1009,7 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     if (!cxp) { crt_rng_free(rng); return fail(CRT_ERR_HIP, "crt_debug_audit_tiles: no launch context"); }
     Context& cx = *cxp;
     std::lock_guard<std::mutex> lock(cx.mu);
-    int rc = ensure_workspace(cx, nx, ny);
+    int rc = ensure_workspace(cx, nx, ny, scene->n_tris);
     if (rc == CRT_OK) rc = ensure_records(cx, scene->n_tris, scene->n_pad);
     hipError_t e = (rc == CRT_OK) ? hipMalloc(&d, 4 * sizeof(unsigned long long)) : hipErrorUnknown;
     if (e == hipSuccess) e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
@@ -1058,7 +1147,7 @@ int crt_last_kernel_times(float* ms3) {
     // binning, ms3[2] = shading kernel (tiled variant) or the brute-force kernel; HIP events on the
     // launch stream of that call.
     if (!ms3) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: null output");
-    Context* cx = g_last_ctx;
+    Context* cx = last_context_locked_lookup();
     if (!cx || !cx->ev_valid) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: no timed kernel launched on this thread (crt_set_kernel_timing)");
     std::lock_guard<std::mutex> lock(cx->mu);
     HIP_TRY(hipEventSynchronize(cx->ev_stop));
@@ -1078,26 +1167,94 @@ float crt_last_kernel_ms(void) {
     return ms3[0];
 }
 
+}  // extern "C"
+
+namespace {
+// What one crt_render call needs besides the scene, kept from call to call per device: the RNG states of the frame, a
+// pristine copy of them right after SetCurandState(seed) (restoring it is a device-to-device copy, 0.04 ms at
+// 1080p, instead of the 0.36 ms skip-ahead kernel — the reference runs SetCurandState once per program,
+// kernel.cu:69-71, and a call of crt_render is defined as "that, then one frame"), and the device colour buffer.
+// Round 2 allocated, initialised and freed all three on every call.  Freed by crt_stream_release(NULL).
+struct OneCall {
+    int device = -1, nx = 0, ny = 0;
+    uint64_t seed = 0;
+    crt_rng* rng = nullptr;
+    uint32_t* d_pristine = nullptr;
+    float* d_rgb = nullptr;
+};
+std::mutex g_onecall_mu;
+std::vector<OneCall> g_onecall;
+
+void onecall_free(OneCall& o) {
+    crt_rng_free(o.rng);
+    if (o.d_pristine) (void)hipFree(o.d_pristine);
+    if (o.d_rgb) (void)hipFree(o.d_rgb);
+    o = OneCall{};
+}
+}  // namespace
+
+void crt_host::release_onecall(int device) {
+    std::lock_guard<std::mutex> lock(g_onecall_mu);
+    for (size_t i = 0; i < g_onecall.size(); ++i)
+        if (g_onecall[i].device == device) {
+            onecall_free(g_onecall[i]);
+            g_onecall.erase(g_onecall.begin() + (long)i);
+            return;
+        }
+}
+
+extern "C" {
+
 int crt_render(int nx, int ny, int samples, int max_depth, int frame_index, const crt_scene* scene,
                const crt_camera* camera, uint64_t seed, float* rgb_out) {
     if (!rgb_out) return fail(CRT_ERR_INVALID, "crt_render: null output");
     if (nx <= 0 || ny <= 0) return fail(CRT_ERR_INVALID, "crt_render: bad image size");
     if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_render: no HIP device");
-    crt_rng* rng = crt_rng_create(0, (int64_t)nx * ny, seed);
-    if (!rng) return CRT_ERR_HIP;
-    float* d_rgb = nullptr;
-    size_t bytes = (size_t)nx * ny * 3 * sizeof(float);
-    hipError_t e = hipMalloc(&d_rgb, bytes);
-    if (e != hipSuccess) { crt_rng_free(rng); return fail(CRT_ERR_HIP, "crt_render: %s", hipGetErrorString(e)); }
-    int rc = crt_render_rows(scene, camera, rng, nx, ny, samples, max_depth, frame_index, 0, ny, d_rgb, nullptr);
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(g_onecall_mu);   // one crt_render at a time per process: it owns the default stream's frame
+    OneCall* o = nullptr;
+    for (OneCall& c : g_onecall)
+        if (c.device == device) o = &c;
+    if (!o) {
+        g_onecall.emplace_back();
+        o = &g_onecall.back();
+        o->device = device;
+    }
+    const size_t bytes = (size_t)nx * ny * 3 * sizeof(float), state_bytes = (size_t)nx * ny * 6 * sizeof(uint32_t);
+    if (o->nx != nx || o->ny != ny || !o->rng) {
+        const int dev = o->device;
+        onecall_free(*o);
+        o->device = dev;
+        o->rng = crt_rng_create(0, (int64_t)nx * ny, seed);   // SetCurandState
+        if (!o->rng) return CRT_ERR_HIP;
+        hipError_t e = hipMalloc(&o->d_rgb, bytes);
+        if (e == hipSuccess) e = hipMalloc(&o->d_pristine, state_bytes);
+        if (e == hipSuccess) e = hipMemcpy(o->d_pristine, o->rng->d_state, state_bytes, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { const int d2 = o->device; onecall_free(*o); o->device = d2; return fail(CRT_ERR_HIP, "crt_render: %s", hipGetErrorString(e)); }
+        o->nx = nx; o->ny = ny; o->seed = seed;
+    } else if (o->seed != seed) {
+        int rc = crt_rng_reset(o->rng, seed);
+        if (rc != CRT_OK) return rc;
+        HIP_TRY(hipMemcpy(o->d_pristine, o->rng->d_state, state_bytes, hipMemcpyDeviceToDevice));
+        o->seed = seed;
+    } else {
+        HIP_TRY(hipMemcpyAsync(o->rng->d_state, o->d_pristine, state_bytes, hipMemcpyDeviceToDevice, nullptr));
+    }
+    int rc = crt_render_rows(scene, camera, o->rng, nx, ny, samples, max_depth, frame_index, 0, ny, o->d_rgb, nullptr);
     if (rc == CRT_OK) {
-        e = hipStreamSynchronize(nullptr);
-        if (e == hipSuccess) e = hipMemcpy(rgb_out, d_rgb, bytes, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(rgb_out, o->d_rgb, bytes, hipMemcpyDeviceToHost);   // ordered after the kernels of the null stream
         if (e != hipSuccess) rc = fail(CRT_ERR_HIP, "crt_render: %s", hipGetErrorString(e));
     }
-    (void)hipFree(d_rgb);
-    crt_rng_free(rng);
     return rc;
+}
+
+int crt_stream_release(void* stream) {
+    if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_stream_release: no HIP device");
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    if (!stream) release_onecall(device);
+    return release_context(device, (hipStream_t)stream);
 }
 
 void crt_to_rgba8(const float* rgb, int nx, int ny, unsigned char* rgba) {

@@ -207,7 +207,9 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
     // createScene.h:42-44,215): the stream continues from where it is when `rng` holds pixel 0.
     const bool have_stream0 = rng && rng->first == 0 && rng->count > 0;
     if (have_stream0) {
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        // stream 0's words are read here and written back below: every render that uses these states — on whatever
+        // stream, non-blocking ones included — has to be done first
+        HIP_TRY(hipDeviceSynchronize());
         uint32_t w[6];
         for (int k = 0; k < 6; ++k)
             HIP_TRY(hipMemcpy(&w[k], rng->d_state + (size_t)k * rng->count, sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -32,10 +32,17 @@ namespace crt_host {
 // the cached occupancy — lives here, one context per (device, stream).  Work enqueued on one
 // stream is ordered by the stream, so launches of one context never overlap; launches on
 // different streams or devices use different contexts and share nothing but read-only scene data.
-// Grow-only; freed at process exit.
+// Lifetime: created at the first launch on (device, stream); buffers grow with the frames and scenes it sees; freed by
+// crt_stream_release (which a host calls before it destroys the stream; crt_multi_free does for its own streams).
+// A hipStream_t is a pointer and the runtime may hand a destroyed stream's address to a new one: every context
+// remembers hipStreamGetId of its stream, and a handle that comes back with another id is a NEW stream — its
+// context is reset (device synchronised once, events and cached occupancy dropped; the scratch buffers carry no
+// state from one frame to the next and are kept).
 struct Context {
+    unsigned long long id = 0;       // unique per context (crt_last_kernel_* look their context up by id)
     int device = 0;
     hipStream_t stream = nullptr;
+    unsigned long long stream_id = 0;   // hipStreamGetId at creation
     std::mutex mu;                   // host-side: two threads enqueueing on the same stream
     crt::TiledWork w{};
     size_t pool_entries = 0, tiles = 0, log_entries = 0;
@@ -49,8 +56,11 @@ struct Context {
 };
 
 Context* context_for(int device, hipStream_t stream);
+// frees the context of (device, stream) if there is one (the stream is synchronised first); CRT_OK either way
+int release_context(int device, hipStream_t stream);
+void release_onecall(int device);   // what crt_render keeps per device
 int ensure_records(Context& cx, int n_tris, int n_pad);
-int ensure_workspace(Context& ws, int nx, int rows);
+int ensure_workspace(Context& ws, int nx, int rows, int n_tris);
 bool have_device();
 void rotation_zero_matrix(float m[9]);
 

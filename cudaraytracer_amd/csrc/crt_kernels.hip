@@ -1119,7 +1119,7 @@ bin_alloc_kernel(TiledWork w, int heavy_min, unsigned shade_blocks, unsigned lon
     }
     // weight class (heaviest first); the last heavy class starts at heavy_min, below is light
     const unsigned weight = fits ? cnt : 0xffffffffu;
-    const unsigned mins[kHeavyClasses] = {1024u, 768u, 512u, 384u, 256u, 192u, 128u, 96u, (unsigned)heavy_min};
+    const unsigned mins[kHeavyClasses] = {768u, 512u, 384u, 256u, 192u, 128u, 96u, 64u, (unsigned)heavy_min};
     const unsigned light_mins[kLightClasses - 1] = {48u, 32u, 16u, 8u, 0u};
     int c = kClasses - 1;
 #pragma unroll
@@ -1443,7 +1443,8 @@ template <bool VREC, int OCC, int WAVES, bool BVH = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
-                   TiledWork w, unsigned long long* __restrict__ stats_in, int dbg_repeat_in, const BvhTiles* __restrict__ bvh) {
+                   TiledWork w, unsigned long long* __restrict__ stats_in, int dbg_repeat_in, const BvhTiles* __restrict__ bvh,
+                   unsigned split_packed) {
     // diagnostics: stats_in[kStatsTimeline] != 0 selects the light-weight timeline (wave start/end times only), which
     // leaves the kernel's timing intact; otherwise the full counters (which roughly double the kernel time)
     const bool timeline = stats_in != nullptr && stats_in[kStatsTimeline] != 0ull;
@@ -1477,9 +1478,15 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 
     // ---- heavy tiles: the classes form one list, heaviest first.  Block b starts with item b
     // (no atomic: all blocks are resident), later items come from one shared cursor.
+    // Sub-items: a heavy tile of weight class c is dealt out as 1 << sl(c) items (sl = 3 bits of split_packed per class),
+    // each the same list for a slab of 8 >> sl rows of the tile's pixels.  The 64 samples of a pixel are a serial
+    // chain (the RNG position of sample k + 1 depends on the rejection loop of sample k), so the time of a shared tile
+    // is 64 x (time of one sample); the (pixel, entry) pairs of one sample split evenly over the slabs, and the blocks
+    // that take the slabs run side by side — the longest chain of a launch gets shorter by the split factor, down to
+    // the master wave's own per-sample work.
     unsigned total_heavy = 0;
 #pragma unroll
-    for (int c = 0; c < kHeavyClasses; ++c) total_heavy += w.counters[kCtrQueueLen + c];
+    for (int c = 0; c < kHeavyClasses; ++c) total_heavy += w.counters[kCtrQueueLen + c] << ((split_packed >> (3 * c)) & 7u);
 #ifndef CRT_PRIO
 #define CRT_PRIO 1
 #endif
@@ -1499,14 +1506,20 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             int c = 0;
             unsigned idx = item;
             for (; c < kHeavyClasses - 1; ++c) {
-                const unsigned len = w.counters[kCtrQueueLen + c];
+                const unsigned len = w.counters[kCtrQueueLen + c] << ((split_packed >> (3 * c)) & 7u);
                 if (idx < len) break;
                 idx -= len;
             }
-            const int tile_id = (int)w.queue[(size_t)c * w.tiles_total + idx];
+            const unsigned sl = (split_packed >> (3 * c)) & 7u;
+            const int sub = (int)(idx & ((1u << sl) - 1u));
+            const int tile_id = (int)w.queue[(size_t)c * w.tiles_total + (idx >> sl)];
             const uint2 desc = w.tile_desc[tile_id];
             const bool walk_all = desc.y == kNoList;
-            const int n_src = walk_all ? n_tris : (int)desc.y;
+            // this item: rows [sub * sub_rows, + sub_rows) of the tile.  A tile without a list (pool overflow) walks every
+            // triangle whatever its pixels: one item for the whole tile, its other items are empty.
+            const int sub_rows = walk_all ? 8 : (8 >> sl);
+            const bool skip_item = (walk_all && sub != 0) || ((tile_id / w.tiles_x) * 8 + sub * sub_rows >= p.row_count);
+            const int n_src = skip_item ? 0 : (walk_all ? n_tris : (int)desc.y);
             const uint32_t* __restrict__ lst = w.pool + desc.x;
             if (timeline) tl_heavy = ((unsigned long long)(unsigned)n_src << 24) | (unsigned)tile_id;
             // List world: the master wave (wave 0) has no slice — it runs the rejection draws of the hit branch while the
@@ -1525,11 +1538,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool interleaved = !walk_all;
             const int cnt_w = (!interleaved || swave < 0 || swave >= n_src) ? 0 : (n_src - swave + kSliceWaves - 1) / kSliceWaves;
             // local rows of the tile (tiles are 8 local rows; they never straddle a strip)
-            const int hx0 = (tile_id % w.tiles_x) * 8, hly0 = (tile_id / w.tiles_x) * 8;
-            const int hx1 = min(hx0 + 8, p.nx), hly1 = min(hly0 + 8, p.row_count);
+            const int hx0 = (tile_id % w.tiles_x) * 8, tly0 = (tile_id / w.tiles_x) * 8;   // tly0: the tile's first local row
+            const int hly0 = tly0 + sub * sub_rows;                                         // hly0: this item's
+            const int hx1 = min(hx0 + 8, p.nx), hly1 = min(hly0 + sub_rows, p.row_count);
             const int xr = hx0 + (lane & 7), lyr = hly0 + (lane >> 3);
             const bool lane_valid = xr < hx1 && lyr < hly1;
-            const int x = min(xr, hx1 - 1), ly = min(lyr, hly1 - 1);   // lanes off the image replay a valid pixel
+            // lanes off the item's slab (or off the image) replay a valid pixel of the tile, unstored and without candidates
+            const int x = min(xr, hx1 - 1), ly = max(min(lyr, hly1 - 1), tly0);
             // Master/worker: wave 0 owns the pixels' RNG streams, generates the 64 rays of each
             // sample and shades; the other waves only trace.  Two barriers per sample:
             // B1 "rays are in LDS", B2 "partial minima are in LDS".
@@ -1606,7 +1621,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);   // no list: a range of all triangles
               }
             };
-            if (BVH && tree_tile) {
+            if (skip_item) {
+                // nothing to render: every wave of the block goes on to the next item
+            } else if (BVH && tree_tile) {
                 if (wave == 0) {
                     BvhView view;
                     view.nodes = bvh->nodes;
@@ -1625,7 +1642,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 // pixel alone from the tile's whole list (general_winner + chain_ok_general, excluding what fails).
                 const BvhTiles& bt = *bvh;
                 const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-                const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, hly0));
+                const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, tly0));
                 const int first_level = __builtin_amdgcn_readfirstlane(
                     tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[0], lane));
                 int tl_sample_bvh = 0;   // timeline mode: (slices done, chains checked) per sample of the first blocks' first tile
@@ -2398,7 +2415,21 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
 #endif
     using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int,
-                             const BvhTiles*);
+                             const BvhTiles*, unsigned);
+    // log2 of the number of row slabs a heavy tile of each weight class (> 768, 512, 384, 256, 192, 128, 96, 64, heavy) is dealt
+    // out as (shade_tiles_kernel: sub-items).  Measured (profiles/r3_tiled/sweep_split_*.txt): splitting the heaviest tiles
+    // x2 .. x8 changes neither the full frame nor the slowest rank of an 8-way split, on either C3 mesh — what bounds a
+    // small launch is the 64-sample chain of EVERY tile that holds geometry (about 2 us per sample whatever the list's
+    // length), not the longest list; splitting the common classes only replicates the master wave's work (+20 .. +90 %).
+    // So the default is no split; the mechanism stays for the tuning build (CRT_SPLIT) and for frames with far longer lists.
+    int split[kHeavyClasses] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef CRT_TUNING
+    if (const char* e = getenv("CRT_SPLIT")) {   // nine digits, e.g. CRT_SPLIT=222222100
+        for (int c = 0; c < kHeavyClasses && e[c] >= '0' && e[c] <= '3'; ++c) split[c] = e[c] - '0';
+    }
+#endif
+    unsigned split_packed = 0;
+    for (int c = 0; c < kHeavyClasses; ++c) split_packed |= (unsigned)split[c] << (3 * c);
     ShadeFn fn;
     if (group == 4) {   // experiment (CRT_SHADE_GROUP=4): half as many waves parked per shared tile, more blocks free for light tiles at once
         occ = 6;
@@ -2443,7 +2474,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)n_blocks), dim3((unsigned)group * 64), 0, stream, p, d_rec, d_cls, n_pad, d_shade_n,
-                       d_state, d_rgb, w, d_stats, dbg_repeat, d_bvh_tiles);
+                       d_state, d_rgb, w, d_stats, dbg_repeat, d_bvh_tiles, split_packed);
     return hipGetLastError();
 }
 

@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -79,6 +80,26 @@ const Rccl& rccl() {
             return fail(CRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// Test hook (crt_debug_inject_send_failure): the next `count` ncclSend calls of this library report ncclInternalError
+// WITHOUT reaching RCCL — the error paths of the exchange step must close the group, drain the streams and restore
+// the caller's device (tests/test_gpu_multi.py).
+std::atomic<int> g_fail_sends{0};
+
+ncclResult_t send_or_injected_failure(const Rccl& R, const void* buf, size_t count, int peer, ncclComm_t comm, hipStream_t stream) {
+    int left = g_fail_sends.load();
+    while (left > 0 && !g_fail_sends.compare_exchange_weak(left, left - 1)) {}
+    if (left > 0) return ncclInternalError;
+    return R.Send(buf, count, ncclFloat, peer, comm, stream);
+}
+
+// First error of a grouped exchange: recorded, not returned, so that ncclGroupEnd always runs.
+struct FirstError {
+    ncclResult_t rc = ncclSuccess;
+    const char* what = "";
+    void note(ncclResult_t r, const char* w) { if (r != ncclSuccess && rc == ncclSuccess) { rc = r; what = w; } }
+    bool ok() const { return rc == ncclSuccess; }
+};
+
 bool layout_ok(int nx, int ny, int strip_rows, int world) {
     return nx > 0 && ny > 0 && world > 0 && strip_rows > 0 && (world == 1 || strip_rows % 32 == 0);
 }
@@ -117,18 +138,30 @@ int crt_gather_strips(const float* d_piece, int nx, int ny, int strip_rows, int 
     if (!R.ok) return fail(CRT_ERR_UNSUPPORTED, "crt_gather_strips: RCCL (librccl.so.1) cannot be loaded: %s", dlerror());
     ncclComm_t comm = (ncclComm_t)nccl_comm;
     hipStream_t stream = (hipStream_t)stream_;
-    // Every rank, the root included, sends its piece to rank 0; the root posts one receive per rank.
+    // Every rank, the root included, sends its piece to rank 0; the root posts one receive per rank.  An error inside
+    // the group is recorded and the group is CLOSED all the same: a thread that returned between GroupStart and
+    // GroupEnd would leave every later RCCL call of that thread swallowed by the open group.
     NCCL_TRY(R.GroupStart());
-    if (my_rows > 0) NCCL_TRY(R.Send(d_piece, (size_t)my_rows * nx * 3, ncclFloat, 0, comm, stream));
-    if (rank == 0)
-        for (int r = 0; r < world; ++r) {
+    FirstError err;
+    if (my_rows > 0) err.note(send_or_injected_failure(R, d_piece, (size_t)my_rows * nx * 3, 0, comm, stream), "ncclSend");
+    if (rank == 0 && err.ok())
+        for (int r = 0; r < world && err.ok(); ++r) {
             if ((long long)r * strip_rows >= ny) break;   // ranks beyond the last strip own nothing
             const int rows = crt_strip_rows(ny, r, strip_rows, world);
-            NCCL_TRY(R.Recv(d_parts + (size_t)r * part_stride, (size_t)rows * nx * 3, ncclFloat, r, comm, stream));
+            err.note(R.Recv(d_parts + (size_t)r * part_stride, (size_t)rows * nx * 3, ncclFloat, r, comm, stream), "ncclRecv");
         }
-    NCCL_TRY(R.GroupEnd());
+    err.note(R.GroupEnd(), "ncclGroupEnd");
+    if (!err.ok()) {
+        (void)hipStreamSynchronize(stream);   // whatever part of the exchange was enqueued has left the stream when this returns
+        return fail(CRT_ERR_HIP, "crt_gather_strips: %s failed: %s", err.what, R.GetErrorString(err.rc));
+    }
     if (rank == 0) HIP_TRY(crt::launch_assemble_strips(d_parts, part_stride, nx, ny, strip_rows, world, d_full, stream));
     return CRT_OK;
+}
+
+int crt_debug_inject_send_failure(int count) {
+    const int prev = g_fail_sends.exchange(count < 0 ? 0 : count);
+    return prev;
 }
 
 }  // extern "C"
@@ -156,6 +189,7 @@ struct crt_multi {
     const crt_camera* job_camera = nullptr;
     const float* job_points = nullptr;
     int job_samples = 0, job_max_depth = 0, job_frame = 0, job_n_points = 0;
+    int job_variant = 0, job_timing = 1;   // the CALLER's crt_set_kernel_variant / crt_set_kernel_timing (per-thread settings; the workers are other threads)
     std::vector<int> job_rc;
     std::vector<std::string> job_err;
 };
@@ -175,6 +209,8 @@ void worker_main(crt_multi* m, int g) {
             seen = m->generation;
         }
         int rc = CRT_OK;
+        crt_set_kernel_variant(m->job_variant);
+        crt_set_kernel_timing(m->job_timing);
         if (m->job_points) rc = crt_scene_update_pose(m->scene[g], m->job_points, m->job_n_points, m->stream[g]);
         if (rc == CRT_OK && m->job_camera && m->rng[g])
             rc = crt_render_strips(m->scene[g], m->job_camera, m->rng[g], m->nx, m->ny, m->job_samples, m->job_max_depth,
@@ -230,7 +266,10 @@ void crt_multi_free(crt_multi* m) {
             if (m->parts) (void)hipFree(m->parts);
             if (m->full) (void)hipFree(m->full);
         }
-        if (g < (int)m->stream.size() && m->stream[g]) (void)hipStreamDestroy(m->stream[g]);
+        if (g < (int)m->stream.size() && m->stream[g]) {
+            (void)crt_stream_release(m->stream[g]);   // the launch context of this stream (records, binning scratch, events)
+            (void)hipStreamDestroy(m->stream[g]);
+        }
     }
     (void)hipSetDevice(prev);
     delete m;
@@ -285,6 +324,8 @@ crt_multi* crt_multi_create(const float* points, int n_points, const float* idx3
 
 int crt_multi_update_pose(crt_multi* m, const float* new_points, int n_points) {
     if (!m || !new_points) return fail(CRT_ERR_INVALID, "crt_multi_update_pose: null argument");
+    m->job_variant = crt_set_kernel_variant(0);
+    crt_set_kernel_variant(m->job_variant);
     m->job_camera = nullptr;
     m->job_points = new_points;
     m->job_n_points = n_points;
@@ -293,36 +334,63 @@ int crt_multi_update_pose(crt_multi* m, const float* new_points, int n_points) {
     return rc;
 }
 
+namespace {
+// every stream of the renderer idle, the caller's device current again: the state every exit of crt_multi_render leaves
+hipError_t drain_and_restore(crt_multi* m, int prev) {
+    hipError_t first = hipSuccess;
+    for (int g = 0; g < m->n; ++g) {
+        hipError_t e = hipSetDevice(m->dev[g]);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->stream[g]);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    (void)hipSetDevice(prev);
+    return first;
+}
+}  // namespace
+
 int crt_multi_render(crt_multi* m, const crt_camera* camera, int samples, int max_depth, int frame_index, float* rgb_out) {
     if (!m || !camera) return fail(CRT_ERR_INVALID, "crt_multi_render: null argument");
     const Rccl& R = rccl();
+    int prev = 0;
+    (void)hipGetDevice(&prev);
     m->job_camera = camera;
     m->job_points = nullptr;
     m->job_samples = samples; m->job_max_depth = max_depth; m->job_frame = frame_index;
+    m->job_variant = crt_set_kernel_variant(0);          // read the calling thread's settings (the setters return the previous value)
+    crt_set_kernel_variant(m->job_variant);
+    m->job_timing = crt_set_kernel_timing(1);
+    crt_set_kernel_timing(m->job_timing);
     int rc = run_job(m);                       // every device has its strips enqueued on its stream
     m->job_camera = nullptr;
-    if (rc != CRT_OK) return rc;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-    // one grouped send/recv over all communicators of this process, then the reassembly on device 0
-    NCCL_TRY(R.GroupStart());
-    for (int g = 0; g < m->n; ++g) {
-        const int rows = ((long long)g * kStripRows < m->ny) ? crt_strip_rows(m->ny, g, kStripRows, m->n) : 0;
-        if (rows == 0) continue;
-        NCCL_TRY(R.Send(m->piece[g], (size_t)rows * m->nx * 3, ncclFloat, 0, m->comm[g], m->stream[g]));
-        NCCL_TRY(R.Recv(m->parts + (size_t)g * m->part_stride, (size_t)rows * m->nx * 3, ncclFloat, g, m->comm[0], m->stream[0]));
+    if (rc != CRT_OK) {                        // some device failed to enqueue: the others have work in flight — drain it
+        const std::string text = crt_last_error();
+        (void)drain_and_restore(m, prev);
+        return fail(rc, "%s", text.c_str());
     }
-    NCCL_TRY(R.GroupEnd());
-    HIP_TRY(hipSetDevice(m->dev[0]));
-    hipError_t e = crt::launch_assemble_strips(m->parts, m->part_stride, m->nx, m->ny, kStripRows, m->n, m->full, m->stream[0]);
+    // one grouped send/recv over all communicators of this process, then the reassembly on device 0.  Errors inside
+    // the group are recorded; the group is always closed, the streams drained and the caller's device restored.
+    FirstError err;
+    err.note(R.GroupStart(), "ncclGroupStart");
+    if (err.ok()) {
+        for (int g = 0; g < m->n && err.ok(); ++g) {
+            const int rows = ((long long)g * kStripRows < m->ny) ? crt_strip_rows(m->ny, g, kStripRows, m->n) : 0;
+            if (rows == 0) continue;
+            err.note(send_or_injected_failure(R, m->piece[g], (size_t)rows * m->nx * 3, 0, m->comm[g], m->stream[g]), "ncclSend");
+            if (err.ok())
+                err.note(R.Recv(m->parts + (size_t)g * m->part_stride, (size_t)rows * m->nx * 3, ncclFloat, g, m->comm[0], m->stream[0]), "ncclRecv");
+        }
+        err.note(R.GroupEnd(), "ncclGroupEnd");
+    }
+    if (!err.ok()) {
+        (void)drain_and_restore(m, prev);
+        return fail(CRT_ERR_HIP, "crt_multi_render: %s failed: %s", err.what, R.GetErrorString(err.rc));
+    }
+    hipError_t e = hipSetDevice(m->dev[0]);
+    if (e == hipSuccess) e = crt::launch_assemble_strips(m->parts, m->part_stride, m->nx, m->ny, kStripRows, m->n, m->full, m->stream[0]);
     if (e == hipSuccess && rgb_out)
         e = hipMemcpyAsync(rgb_out, m->full, (size_t)m->nx * m->ny * 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream[0]);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->stream[0]);
-    for (int g = 1; g < m->n && e == hipSuccess; ++g) {   // the senders' streams are done once the root has everything; cheap
-        e = hipSetDevice(m->dev[g]);
-        if (e == hipSuccess) e = hipStreamSynchronize(m->stream[g]);
-    }
-    (void)hipSetDevice(prev);
+    const hipError_t e2 = drain_and_restore(m, prev);   // the root first has everything, then the senders' streams are done: cheap
+    if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return fail(CRT_ERR_HIP, "crt_multi_render: %s", hipGetErrorString(e));
     return CRT_OK;
 }

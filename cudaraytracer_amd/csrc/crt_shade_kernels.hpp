@@ -193,54 +193,71 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
     const V3 cam_o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
     const float fnx = (float)p.nx, fny = (float)p.ny;
     float colx = 0.0f, coly = 0.0f, colz = 0.0f;
-    for (int smp = 0; smp < p.samples; ++smp) {
-        const float u = ((float)x + xw_uniform(rs)) / fnx;              // render.h:116
-        const float v = ((float)y + xw_uniform(rs)) / fny;              // render.h:117
-        if (pixel_index == 0) {                                         // get_ray's lens sample from state[0] (render.h:118): DESIGN.md §1
-            float px, py;
-            do {
-                px = xw_uniform_2m1(rs);
-                py = xw_uniform_2m1(rs);
-            } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);
+    // One loop over RAYS, not over samples: every trip, each lane that has a path in flight traces its next ray —
+    // the primary ray of its next sample or the next bounce of `shade` — so a lane whose path ended does not wait for
+    // the longest path of the wavefront before it starts its next sample (the wavefront's time is the longest SUM of
+    // a pixel's path lengths instead of the sum over samples of the longest path; the launch used to wait for its
+    // longest chains of bounces: DESIGN.md §4.8).  A pixel's own order of operations — u, v, lens draws, then per
+    // bounce the scatter draws — is unchanged, and its stream is its own, so pixels and states are the same bits.
+    // The wave votes inside the traversals are taken over the lanes that trace in that trip.
+    int smp = 0, depth = 0, levels = 0;
+    bool in_flight = false;
+    V3 r_o = cam_o, r_d = V3{0.0f, 0.0f, 0.0f};
+    for (;;) {
+        if (!in_flight && smp < p.samples) {                            // render.h:115-118: the next sample of this pixel
+            const float u = ((float)x + xw_uniform(rs)) / fnx;          // render.h:116
+            const float v = ((float)y + xw_uniform(rs)) / fny;          // render.h:117
+            if (pixel_index == 0) {                                     // get_ray's lens sample from state[0] (render.h:118): DESIGN.md §1
+                float px, py;
+                do {
+                    px = xw_uniform_2m1(rs);
+                    py = xw_uniform_2m1(rs);
+                } while (px * px + py * py + 0.0f * 0.0f >= 1.0f);
+            }
+            r_o = cam_o;
+            r_d = camera_direction(p.cam, u, v);
+            depth = max_depth;
+            levels = 0;
+            in_flight = true;
+            ++smp;
         }
-        V3 r_o = cam_o, r_d = camera_direction(p.cam, u, v);
-        V3 L;
-        if (shader == 1) {
-            // shade(r, world, max_depth, state), render.h:48-67.  Going down: one level per scattering
-            // hit (its material index is kept); the chain ends with the sky (miss), or with
-            // emitted + 0.1 (depth exhausted, or the material did not scatter).  The wave votes inside
-            // the traversals are taken over the lanes that are still bouncing.
-            int levels = 0;
-            for (int depth = max_depth;; --depth) {
-                const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode);
+        if (__builtin_amdgcn_ballot_w64(in_flight) == 0ull) break;
+        if (in_flight) {
+            const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode);
+            V3 L = V3{0.0f, 0.0f, 0.0f};
+            bool done = true;
+            if (shader == 1) {
+                // shade(r, world, depth, state), render.h:48-67.  Going down: one level per scattering hit (its material
+                // index is kept); the chain ends with the sky (miss), or with emitted + 0.1 (depth exhausted, or the
+                // material did not scatter).
                 if (rec.idx < 0) {
                     L = sky_of(r_d);                                    // render.h:65
-                    break;
-                }
-                const int mi = sc.material_of ? sc.material_of[rec.idx] : 0;
-                const MaterialPOD m = sc.materials[mi];
-                V3 att, s_o, s_d;
-                if (depth > 0 && scatter_dev(m, r_d, rec, att, s_o, s_d, rs)) {   // render.h:58
-                    level_mat[levels][threadIdx.x] = (unsigned short)mi;
-                    ++levels;
-                    r_o = s_o;
-                    r_d = s_d;
                 } else {
-                    const V3 emitted = (m.kind == 3) ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : V3{0.0f, 0.0f, 0.0f};
-                    L = V3{emitted.x + 0.1f, emitted.y + 0.1f, emitted.z + 0.1f};   // render.h:62
-                    break;
+                    const int mi = sc.material_of ? sc.material_of[rec.idx] : 0;
+                    const MaterialPOD m = sc.materials[mi];
+                    V3 att, s_o, s_d;
+                    if (depth > 0 && scatter_dev(m, r_d, rec, att, s_o, s_d, rs)) {   // render.h:58
+                        level_mat[levels][threadIdx.x] = (unsigned short)mi;
+                        ++levels;
+                        --depth;
+                        r_o = s_o;
+                        r_d = s_d;
+                        done = false;
+                    } else {
+                        const V3 emitted = (m.kind == 3) ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : V3{0.0f, 0.0f, 0.0f};
+                        L = V3{emitted.x + 0.1f, emitted.y + 0.1f, emitted.z + 0.1f};   // render.h:62
+                    }
                 }
-            }
-            // Coming back up: emitted + attenuation * (deeper result), render.h:59; a material that
-            // scattered is not a light, so emitted = vec3(0,0,0) (material.h:49-53).
-            for (int k = levels - 1; k >= 0; --k) {
-                const MaterialPOD m = sc.materials[level_mat[k][threadIdx.x]];
-                const V3 att = (m.kind == 2) ? V3{1.0f, 1.0f, 1.0f} : V3{m.albedo[0], m.albedo[1], m.albedo[2]};
-                L = V3{0.0f + att.x * L.x, 0.0f + att.y * L.y, 0.0f + att.z * L.z};
-            }
-        } else {
-            const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode);
-            if (rec.idx < 0) {
+                if (done) {
+                    // Coming back up: emitted + attenuation * (deeper result), render.h:59; a material that
+                    // scattered is not a light, so emitted = vec3(0,0,0) (material.h:49-53).
+                    for (int k = levels - 1; k >= 0; --k) {
+                        const MaterialPOD m = sc.materials[level_mat[k][threadIdx.x]];
+                        const V3 att = (m.kind == 2) ? V3{1.0f, 1.0f, 1.0f} : V3{m.albedo[0], m.albedo[1], m.albedo[2]};
+                        L = V3{0.0f + att.x * L.x, 0.0f + att.y * L.y, 0.0f + att.z * L.z};
+                    }
+                }
+            } else if (rec.idx < 0) {
                 L = sky_of(r_d);                                        // render.h:85,101
             } else if (shader == 2) {
                 L = rec.normal;                                         // shade_normal, render.h:98
@@ -255,10 +272,13 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
                 L = V3{0.2f * ((t * att.x) * sky.x) + emitted.x, 0.2f * ((t * att.y) * sky.y) + emitted.y,
                        0.2f * ((t * att.z) * sky.z) + emitted.z};
             }
+            if (done) {
+                colx += L.x;                                            // render.h:119-121
+                coly += L.y;
+                colz += L.z;
+                in_flight = false;
+            }
         }
-        colx += L.x;                                                    // render.h:119-121
-        coly += L.y;
-        colz += L.z;
     }
     // col /= float(ns); sqrt; clip (render.h:123-128, vec3.h:182-189,119-131)
     const float k = (float)(1.0 / (double)(float)p.samples);

@@ -108,6 +108,66 @@ def dragon1m():
     return displaced_sphere(500, 1000)
 
 
+def midpoint_subdivide(points, tris):
+    """One level of midpoint subdivision: every triangle (a, b, c) becomes (a, ab, ca), (ab, b, bc), (ca, bc, c),
+    (ab, bc, ca) — same orientation, the four children adjacent in the list — with one float32 midpoint
+    0.5 * (p_a + p_b) per undirected edge.  points [n, 3] float32, tris [m, 3] int (0-based)."""
+    tris = np.asarray(tris, dtype=np.int64)
+    e = np.concatenate([tris[:, [0, 1]], tris[:, [1, 2]], tris[:, [2, 0]]], axis=0)
+    e.sort(axis=1)
+    key = e[:, 0] * (len(points) + 1) + e[:, 1]
+    uniq, first, inverse = np.unique(key, return_index=True, return_inverse=True)
+    ends = e[first]
+    mid = (np.float32(0.5) * (points[ends[:, 0]] + points[ends[:, 1]])).astype(np.float32)
+    m = len(tris)
+    ab, bc, ca = (inverse[0:m] + len(points)), (inverse[m:2 * m] + len(points)), (inverse[2 * m:3 * m] + len(points))
+    a, b, c = tris[:, 0], tris[:, 1], tris[:, 2]
+    out = np.stack([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1), np.stack([ab, bc, ca], 1)], axis=1)
+    return np.concatenate([points, mid], axis=0).astype(np.float32), out.reshape(-1, 3)
+
+
+def small_bunny_arrays():
+    """The reference-held mesh CudaTest/objects/small_bunny.obj as arrays (2503 points, already x100 and mean-centred by
+    the loader rule; 4968 faces, 1-based float indices): the data fixture tests/golden/small_bunny_64x64x4.npz
+    (tools/make_golden.py wrote it from the OBJ file; the GPU box has no reference tree)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, "tests", "golden", "small_bunny_64x64x4.npz"))
+    return g["points"].astype(np.float32), (g["idx"].astype(np.int64) - 1)
+
+
+def bunny_ground_100k(index_base=1):
+    """SURVEY §8d's other C3 mesh, without a pole: small_bunny midpoint-subdivided twice (4968 x 16 = 79 488 triangles)
+    standing on a ground grid of 641 x 16 cells (20 512 triangles) = 100 000.  The bunny is scaled x25 (about 390 units
+    tall, the size of the lat-long mesh); the ground lies at the bunny's lowest point, x in [-801.25, 801.25] (cells of
+    2.5), z in [-400, 400] (cells of 50), counter-clockwise seen from above like the bunny's faces seen from outside."""
+    pts, tris = small_bunny_arrays()
+    pts = (pts * np.float32(25.0)).astype(np.float32)
+    for _ in range(2):
+        pts, tris = midpoint_subdivide(pts, tris)
+    assert len(tris) == 79488
+    nxc, nzc = 641, 16
+    y0 = np.float32(pts[:, 1].min())
+    gx = (np.float32(-801.25) + np.float32(2.5) * np.arange(nxc + 1, dtype=np.float32)).astype(np.float32)
+    gz = (np.float32(-400.0) + np.float32(50.0) * np.arange(nzc + 1, dtype=np.float32)).astype(np.float32)
+    zz, xx = np.meshgrid(gz, gx, indexing="ij")                       # point (k, i) = row k (z), column i (x)
+    ground = np.stack([xx, np.full_like(xx, y0), zz], axis=-1).reshape(-1, 3).astype(np.float32)
+    kk, ii = np.meshgrid(np.arange(nzc), np.arange(nxc), indexing="ij")
+    p00 = kk * (nxc + 1) + ii
+    p01, p10, p11 = p00 + 1, p00 + (nxc + 1), p00 + (nxc + 1) + 1     # +x, +z, both
+    base = len(pts)
+    # seen from +y with +x to the right and +z towards the viewer, (p00, p10, p11) and (p00, p11, p01) run counter-clockwise
+    g1 = np.stack([p00, p10, p11], axis=-1).reshape(-1, 3) + base
+    g2 = np.stack([p00, p11, p01], axis=-1).reshape(-1, 3) + base
+    gt = np.empty((len(g1) * 2, 3), dtype=np.int64)
+    gt[0::2], gt[1::2] = g1, g2
+    allp = np.concatenate([pts, ground], axis=0).astype(np.float32)
+    allt = np.concatenate([tris, gt], axis=0)
+    assert len(allt) == 100000
+    return dict(points=allp, idx=(allt + index_base).astype(np.float32), normals=None, index_base=index_base,
+                camera=dict(REFERENCE_CAMERA))
+
+
 # ---- the BASELINE.json frames, ONE definition for bench.py and the tests -------------------
 # name -> (nx, ny, spp, n_lat, n_lon): the mesh is written as an OBJ file (1-based `f a b c`
 # records) and read back through the OBJ loader (mean centring, Loader/obj_loader.h:120-133),
@@ -116,12 +176,15 @@ BASELINE_FRAMES = {
     "C3": (1920, 1080, 64, 200, 250),      # configs[2]: 100 000 triangles, 1 GPU
     "C4": (1920, 1080, 256, 200, 250),     # configs[3]: same mesh, 256 spp, 8-way split
     "C5": (3840, 2160, 64, 500, 1000),     # configs[4]: 1 000 000 triangles
+    "C3B": (1920, 1080, 64, "bunny_ground", 0),   # configs[2] on SURVEY §8d's other mesh: subdivided small_bunny + ground grid, no pole
 }
 
 
 def baseline_mesh(name):
     """The mesh of a BASELINE frame before the OBJ round trip (index_base 1)."""
     n_lat, n_lon = BASELINE_FRAMES[name][3:5]
+    if n_lat == "bunny_ground":
+        return bunny_ground_100k(index_base=1)
     return displaced_sphere(n_lat, n_lon, radius=200.0, centre=(0.0, 0.0, 0.0), index_base=1)
 
 
@@ -130,7 +193,7 @@ def baseline_obj(name, folder):
     import os
     nx, ny, spp = BASELINE_FRAMES[name][:3]
     n_lat, n_lon = BASELINE_FRAMES[name][3:5]
-    path = os.path.join(folder, "synthetic_%dx%d.obj" % (n_lat, n_lon))
+    path = os.path.join(folder, ("synthetic_%dx%d.obj" % (n_lat, n_lon)) if n_lat != "bunny_ground" else "synthetic_bunny_ground.obj")
     if not os.path.exists(path):
         write_obj(path, baseline_mesh(name))
     return path, nx, ny, spp

@@ -30,6 +30,12 @@
  *     the reference cannot be built here; see oracle/crt_oracle.h).
  *   - there is NO CPU fallback: every compute entry point fails with CRT_ERR_NO_DEVICE
  *     when no HIP device is usable
+ *   - ONE HIP runtime per process: libcrt_hip.so asks the loader for libamdhip64.so.7 (by SONAME).  A C/C++ host that
+ *     links the ROCm runtime itself shares that copy and has nothing to do.  A host that carries its OWN copy of the
+ *     runtime under another file name (PyTorch wheels bundle torch/lib/libamdhip64.so) must load that copy BEFORE
+ *     libcrt_hip.so, so that the SONAME is already satisfied; loaded the other way round the process holds two HIP
+ *     runtimes and the second one sees no device (torch.cuda.is_available() == False, or CRT_ERR_NO_DEVICE here).
+ *     cudaraytracer_amd/_lib.py imports torch first for that reason; INTEGRATION.md "One HIP runtime per process".
  */
 #ifndef CRT_H
 #define CRT_H
@@ -177,9 +183,14 @@ int crt_render_strips(const crt_scene *scene, const crt_camera *camera, crt_rng 
                       int ny, int samples, int max_depth, int frame_index, int first_strip,
                       int strip_rows, int strip_step, float *d_rgb, void *stream);
 
-/* replaces: one frame of renderListAnimation (core/render.h:159-189): allocates device
- * RNG states and a device colour buffer, renders the full image on the current device,
- * synchronises and copies nx*ny*3 floats to the HOST buffer rgb_out. */
+/* replaces: SetCurandState + one frame of renderListAnimation (core/render.h:159-189, kernel.cu:69-71): RNG states
+ * from `seed`, the full image on the current device's default stream, then nx*ny*3 floats copied to the HOST
+ * buffer rgb_out.  The one-call surface `render(width, height, samples, hitable_list, camera) -> RGB buffer`.
+ * The states (with a pristine copy that makes a repeated call with the same image size and seed a device-to-device
+ * restore instead of a re-initialisation) and the device colour buffer are kept per device between calls and freed
+ * by crt_stream_release(NULL).  Calls are serialised per process.  A frame LOOP should use crt_rng_create +
+ * crt_render_rows on its own stream and buffers: the states then advance from frame to frame as the reference's
+ * do (core/render.h:174-186) and nothing crosses PCIe unless the host asks. */
 int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
                const crt_scene *scene, const crt_camera *camera, uint64_t seed,
                float *rgb_out);
@@ -346,6 +357,15 @@ int crt_last_kernel_times(float *ms3);
  * While off, crt_last_kernel_* fail with CRT_ERR_INVALID.  Returns the previous value. */
 int crt_set_kernel_timing(int enable);
 
+/* Launch contexts.  Everything a render launch writes besides its outputs belongs to a context keyed by (current
+ * device, stream), created at the first launch on that stream and grown with the frames it sees (at 1920x1080 and
+ * 100 000 triangles: about 40 MB).  A host that creates streams as it goes calls this BEFORE hipStreamDestroy (no
+ * launch of this library may be in progress on the stream from another thread): the stream is synchronised and its
+ * context freed.  stream = NULL releases the default stream's context and what crt_render keeps.  CRT_OK also when
+ * there is nothing to release.  A stream handle the runtime hands out again after a destroy is recognised by
+ * hipStreamGetId and gets a fresh context state; crt_multi_free releases the contexts of its own streams. */
+int crt_stream_release(void *stream);
+
 /* ---- multi-GPU ------------------------------------------------------------------
  * The reference is single-GPU; this section is the north-star split: strips of
  * `strip_rows` (32) image rows dealt round-robin to `world` ranks, rendered with
@@ -369,15 +389,28 @@ int crt_assemble_strips(const float *d_parts, int64_t part_stride, int nx, int n
  * ranks pass NULL for both.  Enqueues: ncclGroupStart; ncclSend(piece -> 0) on every rank,
  * the root included; on rank 0 one ncclRecv per rank; ncclGroupEnd; then on rank 0 the
  * reassembly kernel.  RCCL is bound at first use (dlopen librccl.so.1): CRT_ERR_UNSUPPORTED if
- * it cannot be loaded. */
+ * it cannot be loaded.  An RCCL error inside the group is reported AFTER the group has been closed and the
+ * stream synchronised, so the calling thread's next RCCL call starts clean. */
 int crt_gather_strips(const float *d_piece, int nx, int ny, int strip_rows, int rank, int world,
                       float *d_parts, int64_t part_stride, float *d_full, void *nccl_comm,
                       void *stream);
 
+/* Test hook: the next `count` ncclSend calls made by this library (crt_gather_strips, crt_multi_render) report
+ * ncclInternalError without reaching RCCL, so that the error paths of the exchange step can be exercised on one
+ * device.  Returns the previous count; 0 switches it off. */
+int crt_debug_inject_send_failure(int count);
+
 /* One process, n_gpus devices (devices 0..n_gpus-1): the scene is replicated, every device gets
  * its strip set's RNG states (seed, stream = global pixel index), a stream and a host worker
  * thread; communicators come from ncclCommInitAll.  replaces: the driver shape of
- * renderListAnimation (core/render.h:159-189) for n_gpus devices. */
+ * renderListAnimation (core/render.h:159-189) for n_gpus devices.
+ * crt_multi_render / crt_multi_update_pose hand the CALLING thread's crt_set_kernel_variant and
+ * crt_set_kernel_timing settings to the workers for that job (the workers' own crt_last_kernel_* are not
+ * reachable: time a multi-device frame from outside).  Every exit of crt_multi_render — success, a device that
+ * failed to enqueue, an RCCL error inside the grouped exchange — leaves the NCCL group closed, all of the
+ * renderer's streams idle and the caller's device current.  crt_multi_free releases the launch contexts of its
+ * streams.  UNTESTED ON MORE THAN ONE DEVICE until a multi-GPU run exists: the n_gpus > 1
+ * exchange has only ever executed with n_gpus = 1 and under gloo on CPU. */
 typedef struct crt_multi crt_multi;
 crt_multi *crt_multi_create(const float *points, int n_points, const float *idx3f, int n_tris,
                             const float *face_normals, int index_base, const float albedo[3],

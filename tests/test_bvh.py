@@ -77,6 +77,68 @@ def test_oracle_tree_shape(oracle):
     assert probe[0] == states[0]
 
 
+# ---- hand-derived trees: expected leaf orders that come from READING Thrust's sequential sort, not from running any
+# restatement of it.  thrust::sort inside a device thread = sequential iterative stable merge sort
+# (thrust/system/detail/sequential/stable_merge_sort.inl: insertion_sort per 32 elements, then merge of adjacent runs);
+# the comparator BoxCompare (bvh.h:9-45) is comp(a, b) = !(key(a) - key(b) < 0) = key(a) >= key(b): "a goes before b when
+# its key is not smaller" — descending, and TRUE on equal keys.
+#   insertion_sort (insertion_sort.h): for i = 1..n-1: tmp = x[i]; if comp(tmp, x[0]) move x[0..i) up one and put tmp first;
+#     else shift x[k] up while comp(tmp, x[k]) from k = i-1 downwards, drop tmp behind the first k that fails.
+#   merge (merge.inl): while both runs hold elements: take from run 2 if comp(*run2, *run1) else from run 1; append rests.
+# Every triangle below has the same box minimum on all three axes, so the drawn axes (stream 0) do not matter.
+#
+# (A) keys 1, 1, 2, 1, 0 (triangles 0..4), worked by hand:
+#   root sort:  [0 1 2 3 4] -> i=1: comp(1;0) 1>=1 true  -> [1 0 2 3 4]
+#                           -> i=2: comp(2;1) 2>=1 true  -> [2 1 0 3 4]
+#                           -> i=3: comp(3;2) 1>=2 false; comp(3;0) 1>=1 true, comp(3;1) 1>=1 true, comp(3;2) false -> [2 3 1 0 4]
+#                           -> i=4: comp(4;2) 0>=2 false; comp(4;0) 0>=1 false                                       -> [2 3 1 0 4]
+#   left  = first 5/2 = 2: [2 3], keys 2, 1: i=1: comp(3;2) false, comp(3;2) false -> [2 3]: leaf (2, 3)
+#   right = [1 0 4], keys 1, 1, 0: i=1: comp(0;1) 1>=1 true -> [0 1 4]; i=2: comp(4;0) false, comp(4;1) false -> [0 1 4]
+#     left = [0]: leaf (0);  right = [1 4], keys 1, 0: stays: leaf (1, 4)
+#   leaves in preorder: (2, 3) (0) (1, 4); 5 nodes.
+# (B) n equal keys: insertion sort REVERSES a run (every tmp satisfies comp(tmp, first)); merge takes all of run 2, then
+#   run 1 — so two reversed runs [31..0], [n-1..32] merge to [n-1..0], and so on up: every node reverses its span, then
+#   splits n/2 | n - n/2.
+HAND_TREE_A_KEYS = [1.0, 1.0, 2.0, 1.0, 0.0]
+HAND_TREE_A_ORDER = [2, 3, 0, 1, 4]
+
+
+def equal_key_order(ids):
+    ids = ids[::-1]
+    if len(ids) <= 2:
+        return ids
+    return equal_key_order(ids[:len(ids) // 2]) + equal_key_order(ids[len(ids) // 2:])
+
+
+def keyed_triangles(keys):
+    """Triangle i has box minimum (k_i, k_i, k_i) and a box that is thick on every axis."""
+    pts, idx = [], []
+    for i, k in enumerate(keys):
+        pts += [(k, k, k), (k + 1.0, k + 2.0, k), (k, k + 1.0, k + 3.0)]
+        idx.append((3 * i, 3 * i + 1, 3 * i + 2))
+    return dict(points=np.array(pts, dtype=np.float32), idx=np.array(idx, dtype=np.float32), normals=None, index_base=0,
+                camera=dict(scenes.REFERENCE_CAMERA))
+
+
+HAND_TREES = [("A", HAND_TREE_A_KEYS, HAND_TREE_A_ORDER),
+              ("B5", [3.0] * 5, equal_key_order(list(range(5)))),
+              ("B70", [0.5] * 70, equal_key_order(list(range(70)))),       # three runs of 32, 32, 6: two merge passes
+              ("B33", [7.0] * 33, equal_key_order(list(range(33))))]
+
+
+@pytest.mark.parametrize("name,keys,order", HAND_TREES, ids=[t[0] for t in HAND_TREES])
+def test_oracle_leaf_order_equals_the_hand_derived_tree(oracle, name, keys, order):
+    # (B) for n = 5 by hand: root reverses to [4 3 2 1 0]; left [4 3] reverses to the leaf (3, 4); right [2 1 0] reverses to [0 1 2]:
+    # leaf (0), then [1 2] reverses to the leaf (2, 1)
+    assert equal_key_order(list(range(5))) == [3, 4, 0, 2, 1]
+    w, _ = oracle_scene(oracle, keyed_triangles(keys), 8, 8)
+    bvh = oracle.Bvh(w, oracle.fresh_states(8, 8))
+    assert bvh.order().tolist() == order, name
+    if name == "A":
+        nodes = bvh.nodes()
+        assert len(nodes) == 5 and nodes["isLeaf"].tolist() == [0, 1, 0, 1, 1] and nodes["count"][nodes["isLeaf"] == 1].tolist() == [2, 1, 2]
+
+
 def test_oracle_bvh_semantics_differ_from_the_list_where_the_reference_does(oracle):
     """(a) a triangle behind the eye: the list accepts its negative t (no range test,
     triangle.h:92-99), the BVH never reaches it — AABB::hit starts from t_min = 0.001 (aabb.h:30-43).
@@ -363,3 +425,14 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
             assert api.tiled_stats(0)[6] == n                  # the scene does what it was built for: a tile with all 2050 entries
         assert np.array_equal(bits(rgb), bits(ref)), (kind, variant, int((bits(rgb) != bits(ref)).any(axis=2).sum()))
         assert np.array_equal(st[1:], after[1:]), (kind, variant)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,keys,order", HAND_TREES, ids=[t[0] for t in HAND_TREES])
+def test_gpu_leaf_order_equals_the_hand_derived_tree(gpu, name, keys, order):
+    """The product's restatement of the sort (csrc/crt_bvh.cpp) against the same hand-derived orders."""
+    sc = keyed_triangles(keys)
+    scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    scene.build_bvh(None, 0)
+    _, _, slot_triangle = scene.bvh_export()
+    assert np.asarray(slot_triangle).tolist() == order, name

@@ -3,6 +3,7 @@
 The frames come from cudaraytracer_amd.scenes.baseline_obj — the SAME definition bench.py
 times (OBJ round trip, loader centring, reference camera):
   C3  1920x1080 x 64 spp, 100 000 triangles   (the bench frame)
+  C3B the same configuration on the pole-free mesh (subdivided small_bunny + ground grid), bench.py's second workload
   C4  1920x1080 x 256 spp, 100 000 triangles, the 8 strip sets of an 8-GPU split
   C5  3840x2160 x 64 spp, 1 000 000 triangles
 Bar: the tiled kernels equal the brute-force list walk bit for bit (pixels and RNG states), and
@@ -92,6 +93,37 @@ def test_c3_full_frame_64spp_tiled_equals_brute_force_and_oracle(gpu, oracle, ob
     assert 0.05 < cover < 0.5, cover
     w, ocam = oracle_world(oracle, path, nx, ny)
     for win in silhouette_and_interior(tiled, 8, 4):                     # 2 x 2048 rays x 100 k triangles
+        check_crop(oracle, w, ocam, tiled, nx, ny, spp, win)
+    n_pass, n_missing, n_cull, _ = api.audit_tiles(scene, cam, nx, ny, 4)
+    assert n_pass > 0 and n_missing == 0 and n_cull == 0
+
+
+def test_c3b_bunny_on_ground_64spp_tiled_equals_brute_force_and_oracle(gpu, oracle, obj_dir):
+    """BASELINE configs[2] on SURVEY §8d's OTHER 100 000-triangle mesh — small_bunny midpoint-subdivided twice on a
+    ground grid, no pole fan (scenes.bunny_ground_100k; bench.py reports it as its second workload): the same bar as
+    C3.  Crops: the bunny's silhouette against the sky, its interior, the ground's horizon, the ground in front."""
+    path, scene, cam, nx, ny, spp = load("C3B", obj_dir)
+    assert (nx, ny, spp, scene.n_triangles) == (1920, 1080, 64, 100000)
+    tiled, st_t = render(gpu, scene, cam, nx, ny, spp, variant=2)
+    brute, st_b = render(gpu, scene, cam, nx, ny, spp, variant=1)       # 1.3e13 pair tests
+    assert np.array_equal(bits(tiled), bits(brute))
+    assert np.array_equal(st_t, st_b)
+    assert np.isfinite(tiled).all() and tiled.min() >= 0.0 and tiled.max() <= 1.0
+    m = hit_mask(tiled)
+    assert 0.1 < m.mean() < 0.8, m.mean()
+    r_top = int(np.where(m.any(axis=1))[0][-1])                          # row 0 = image bottom: the tip of an ear
+    r_sil, r_in = r_top - 60, r_top - 200
+    c_sil = int(np.where(m[r_sil])[0][0])
+    cols_in = np.where(m[r_in])[0]
+    col_g = 200                                                          # a column left of the bunny: ground below, sky above
+    r_hor = int(np.where(m[:, col_g])[0][-1])
+    wins = [(r_sil, r_sil + 4, c_sil - 4, c_sil + 4), (r_in, r_in + 4, int(cols_in[len(cols_in) // 2]), int(cols_in[len(cols_in) // 2]) + 8),
+            (r_hor - 1, r_hor + 3, col_g, col_g + 8), (40, 44, 960, 968)]
+    for k, win in enumerate(wins):
+        sub = m[win[0]:win[1], win[2]:win[3]]
+        assert sub.any() and (k not in (0, 2) or not sub.all()), (k, win)   # silhouette and horizon windows hold both
+    w, ocam = oracle_world(oracle, path, nx, ny)
+    for win in wins:                                                     # 4 x 2048 rays x 100 k triangles
         check_crop(oracle, w, ocam, tiled, nx, ny, spp, win)
     n_pass, n_missing, n_cull, _ = api.audit_tiles(scene, cam, nx, ny, 4)
     assert n_pass > 0 and n_missing == 0 and n_cull == 0

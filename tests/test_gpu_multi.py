@@ -237,7 +237,151 @@ def test_bench_line_carries_the_contract_fields(gpu):
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["unit"] == "Mrays/s" and out["dtype"] == "f32"
     assert out["vs_baseline"] is None and out["higher_is_better"] is True and out["data"] == "synthetic" and "workload" in out["config"]
     rf = out["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    # `bound` carries one of the contract's two labels; what actually limits the kernel is in `limiter` (VALU issue), said next to it
+    assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["bound"] in ("hbm", "mfma") and "valu" in rf["limiter"] and rf["bound_note"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["repetitions"] >= 3 and len(cb["seconds"]) == cb["repetitions"] and cb["cpu_model"] and cb["host_cores"] >= 1
+    assert cb["all_cores"]["cores"] == cb["host_cores"] and cb["all_cores"]["value"] > 0
     assert out["parity_crop"] is True and out["parity_crop_hit_pixels"] > 0
+
+
+def test_failed_send_leaves_a_clean_state(gpu, crt_built):
+    """An RCCL error inside the grouped exchange (injected: the library's next ncclSend reports ncclInternalError without
+    reaching RCCL) must not leave the NCCL group open, work in flight or the wrong device current: the call fails, the
+    NEXT call on the same communicator succeeds and delivers the frame.  Both entry points: crt_gather_strips (caller's
+    communicator) and crt_multi_render (the single-process driver)."""
+    sc = scenes.displaced_sphere(24, 30)
+    nx, ny, spp = 200, 120, 2
+    scene, cam = make(sc, nx, ny)
+    want = full_frame(gpu, scene, cam, nx, ny, spp)
+    dev_before = gpu.cuda.current_device()
+    rccl = _rccl()
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(dev_before)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        piece = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+        stride = api.strip_part_stride(nx, ny, 32, 1)
+        parts = gpu.zeros(stride, dtype=gpu.float32, device="cuda")
+        full = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+        stream = gpu.cuda.Stream()
+        gpu.cuda.synchronize()
+        for attempt in range(2):
+            st = api.CurandState.for_strips(nx, ny, 0, 32, 1, 0)
+            api.render_strips(scene, cam, st, nx, ny, spp, 0, 32, 1, piece, stream=stream)
+            if attempt == 0:
+                assert crt_built.crt_debug_inject_send_failure(1) == 0
+                with pytest.raises(_lib.CrtError) as ei:
+                    api.gather_strips(piece, nx, ny, 32, 0, 1, parts, stride, full, comm.value, stream=stream)
+                assert "ncclSend" in str(ei.value)
+                assert crt_built.crt_debug_inject_send_failure(0) == 0          # the injected failure was consumed
+                assert gpu.cuda.current_device() == dev_before
+            else:
+                api.gather_strips(piece, nx, ny, 32, 0, 1, parts, stride, full, comm.value, stream=stream)
+                stream.synchronize()
+                assert np.array_equal(bits(full.cpu().numpy().reshape(ny, nx, 3)), bits(want))
+    finally:
+        crt_built.crt_debug_inject_send_failure(0)
+        rccl.ncclCommDestroy(comm)
+    # the single-process driver
+    m = api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 1)
+    try:
+        crt_built.crt_debug_inject_send_failure(1)
+        with pytest.raises(_lib.CrtError) as ei:
+            m.render(cam, spp)
+        assert "ncclSend" in str(ei.value)
+        assert gpu.cuda.current_device() == dev_before
+        # the failed frame DID advance the RNG states (its strips were rendered before the exchange failed), as a frame
+        # of the reference's loop would: a fresh renderer gives frame 0 again
+    finally:
+        crt_built.crt_debug_inject_send_failure(0)
+        m.close()
+    m = api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 1)
+    try:
+        assert np.array_equal(bits(m.render(cam, spp)), bits(want))
+    finally:
+        m.close()
+
+
+def test_streams_come_and_go_without_growing_device_memory(gpu, crt_built):
+    """A host that makes a fresh stream per task: crt_stream_release before the stream is destroyed frees its launch
+    context (records, binning scratch, events).  100 streams, each used for one tiled frame: free device memory ends where
+    it was after the first; and the renderer of crt_multi_* releases the contexts of its own streams when it is closed."""
+    sc = scenes.displaced_sphere(40, 50)
+    nx, ny, spp = 320, 192, 2
+    scene, cam = make(sc, nx, ny)
+    want = full_frame(gpu, scene, cam, nx, ny, spp)
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    st = api.SetCurandState(nx, ny, 0)
+
+    hip = C.CDLL("libamdhip64.so")        # the HIP runtime this process already holds (torch's): real create / destroy cycles
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    class RawStream:                       # what api.render_rows needs of a stream object
+        def __init__(self, handle):
+            self.cuda_stream = handle
+
+    def one_stream(release=True):
+        h = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(h)) == 0
+        st.reset(0)
+        api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=RawStream(h.value))
+        assert hip.hipStreamSynchronize(h) == 0
+        if release:
+            assert crt_built.crt_stream_release(h) == 0
+        assert hip.hipStreamDestroy(h) == 0
+
+    for _ in range(8):                     # the runtime's own per-stream pools settle
+        one_stream()
+    gpu.cuda.synchronize()
+    free0, _ = gpu.cuda.mem_get_info()
+    for _ in range(100):
+        one_stream()
+    assert np.array_equal(bits(d.cpu().numpy().reshape(ny, nx, 3)), bits(want))
+    gpu.cuda.synchronize()
+    free1, _ = gpu.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), "device memory shrank by %.1f MB over 100 released streams" % ((free0 - free1) / 2**20)
+    assert crt_built.crt_stream_release(C.c_void_p(12345)) == 0                # nothing to release: still CRT_OK
+    def one_renderer():
+        m = api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 1)
+        m.render(cam, spp)
+        m.close()
+
+    one_renderer()                         # RCCL's own first-use allocations
+    gpu.cuda.synchronize()
+    free1, _ = gpu.cuda.mem_get_info()
+    for _ in range(5):
+        one_renderer()
+    gpu.cuda.synchronize()
+    free2, _ = gpu.cuda.mem_get_info()
+    assert free1 - free2 < (16 << 20), "device memory shrank by %.1f MB over 5 renderers" % ((free1 - free2) / 2**20)
+
+
+def test_one_call_render_is_repeatable_and_keeps_its_buffers(gpu, crt_built, oracle):
+    """crt_render = SetCurandState(seed) + one frame into a host buffer: the same seed gives the same frame on every
+    call (the states are restored from the pristine copy), another seed another frame, another size reallocates; the
+    oracle agrees; crt_stream_release(NULL) frees what the calls kept."""
+    sc = scenes.displaced_sphere(16, 20)
+    scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    nx, ny, spp = 96, 80, 3
+    cam = api.init_camera(nx, ny)
+    a = api.render(nx, ny, spp, scene, cam, seed=0)
+    b = api.render(nx, ny, spp, scene, cam, seed=0)
+    c = api.render(nx, ny, spp, scene, cam, seed=7)
+    d = api.render(nx, ny, spp, scene, cam, seed=0)
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(d)) and not np.array_equal(bits(a), bits(c))
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    ocam = oracle.make_camera((0, 100, 1000), (0, 150, 0), (0, 1, 0), 40.0, np.float32(nx) / np.float32(ny), 0.0, 10.0)
+    ref, _ = oracle.render(w, ocam, nx, ny, spp)
+    assert np.array_equal(bits(a), bits(ref))
+    cam2 = api.init_camera(64, 48)
+    e = api.render(64, 48, 2, scene, cam2, seed=0)
+    ocam2 = oracle.make_camera((0, 100, 1000), (0, 150, 0), (0, 1, 0), 40.0, np.float32(64) / np.float32(48), 0.0, 10.0)
+    ref2, _ = oracle.render(w, ocam2, 64, 48, 2)
+    assert np.array_equal(bits(e), bits(ref2))
+    assert crt_built.crt_stream_release(None) == 0
+    assert np.array_equal(bits(api.render(nx, ny, spp, scene, cam, seed=0)), bits(a))

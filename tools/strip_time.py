@@ -1,21 +1,40 @@
 #!/usr/bin/env python3
-"""Kernel time of ONE rank's strip set on the bench scene: strip_time.py [world] [rank]"""
-import os, sys, tempfile
+"""Slowest rank of a W-way strip split of a BASELINE frame, rendered rank by rank on ONE GPU (HIP events per launch):
+    python tools/strip_time.py [frame=C3] [worlds=1,2,4,8] [spp]
+frame: C3 (the lat-long mesh bench.py's headline uses) or C3B (subdivided small_bunny + ground grid, no pole).
+Prints per W: the slowest rank's total / binning / shading ms (best of 5 launches per rank), the ideal T(1)/W, and the
+speed-up before the gather that the slowest rank allows."""
+import os
+import sys
+import tempfile
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import bench
-from cudaraytracer_amd import api
-from cudaraytracer_amd.dist import BandRenderer
-world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-ranks = [int(sys.argv[2])] if len(sys.argv) > 2 else range(world)
-obj = bench.build_scene_obj(tempfile.mkdtemp())
+import torch  # noqa: E402
+from cudaraytracer_amd import api, scenes  # noqa: E402
+from cudaraytracer_amd.dist import BandRenderer  # noqa: E402
+
+frame = sys.argv[1] if len(sys.argv) > 1 else "C3"
+worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8").split(",")]
+obj, nx, ny, spp = scenes.baseline_obj(frame, tempfile.mkdtemp())
+if len(sys.argv) > 3:
+    spp = int(sys.argv[3])
 scene = api.Scene.from_obj(obj, scale=1.0)
-cam = api.init_camera(bench.NX, bench.NY)
-worst = (0, 0, 0)
-for r in ranks:
-    br = BandRenderer(scene, cam, bench.NX, bench.NY, r, world, mode="strips")
-    ts = []
-    for _ in range(5):
-        br.render(64); torch.cuda.synchronize(); ts.append(api.last_kernel_times())
-    worst = max(worst, min(ts))
-print("world %d env %s: slowest rank total/bin/shade ms %.3f %.3f %.3f" % ((world, {k: v for k, v in os.environ.items() if k.startswith("CRT_")}) + worst))
+cam = api.init_camera(nx, ny)
+t1 = None
+for world in worlds:
+    worst, per_rank = (0.0, 0.0, 0.0), []
+    for r in range(world):
+        br = BandRenderer(scene, cam, nx, ny, r, world, mode="strips")
+        ts = []
+        for _ in range(6):
+            br.render(spp)
+            torch.cuda.synchronize()
+            ts.append(tuple(api.last_kernel_times()))
+        best = min(ts[1:])
+        per_rank.append(best[0])
+        worst = max(worst, best)
+    if world == 1:
+        t1 = worst[0]
+    scaling = ("ideal %.3f | speed-up before the gather %.2fx" % (t1 / world, t1 / worst[0])) if t1 else "(no W=1 time in this run)"
+    print("%s %dx%dx%d W=%d: slowest rank total/bin/shade ms %.3f %.3f %.3f | %s | ranks: %s"
+          % (frame, nx, ny, spp, world, worst[0], worst[1], worst[2], scaling, " ".join("%.3f" % x for x in per_rank)), flush=True)

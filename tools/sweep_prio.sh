@@ -10,4 +10,4 @@ d=json.loads(sys.stdin.readline())
 print('PRIO=$1 heavy $2 geom $3 sky $4: ms_per_step %.4f binning %.4f shade %.4f filling %.4f bvh %.4f' % (d['ms_per_step'], d['kernels']['binning']['ms'], d['kernels']['shade_tiles_kernel']['ms'], d['screen_filling_variant']['ms_per_frame'], d['bvh_world']['ms_per_frame']))"
 done
 make -C cudaraytracer_amd/csrc -B ../libcrt_hip.so > /dev/null 2>&1
-python tools/strip_time.py 2>/dev/null | tail -1
+python tools/strip_time.py C3 8 2>/dev/null | tail -1
