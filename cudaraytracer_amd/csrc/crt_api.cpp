@@ -837,7 +837,10 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
                 int row_begin, int row_count, int strip_rows, int strip_step, float* d_rgb, void* stream_, int world,
                 int shader, int max_depth) {
     if (!scene || !camera || !rng || !d_rgb) return fail(CRT_ERR_INVALID, "crt_render_rows: null argument");
-    const bool generic = shader != CRT_SHADER_LAMBERT || !scene->single_lambertian;
+    // LambertShade with a material per triangle rides the tiled kernels too (the material only changes what a hit draws
+    // and returns, crt_kernels.hip: render_pixel<.., MAT>) when they are eligible; variant 1 keeps the generic kernel (A/B)
+    const bool lambert_materials = shader == CRT_SHADER_LAMBERT && !scene->single_lambertian;
+    bool generic = shader != CRT_SHADER_LAMBERT || !scene->single_lambertian;
     if (world == 1 && !scene->bvh) return fail(CRT_ERR_INVALID, "crt_render_rows_bvh: the scene has no BVH (crt_scene_build_bvh)");
     if ((long long)nx * ny > 0x7fffffffLL)
         return fail(CRT_ERR_INVALID, "crt_render_rows: nx*ny exceeds the reference's int pixel_index (core/render.h:111)");
@@ -885,6 +888,26 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     float pos_du = 0.0f, pos_dv = 0.0f, k_slack = 0.0f;
     cam_ok = cam_ok && camera_slacks(camera, &pos_du, &pos_dv, &k_slack);
     const bool tiled_ok = scene->tiled_safe && cam_ok && scene->n_tris > 0;
+    crt::MatView mat_view;
+    const crt::MatView* materials = nullptr;
+    if (lambert_materials && tiled_ok) {
+        // list world: any tiled variant with staged records; BVH world: only where the tiled mode below is taken (its
+        // conditions, restated: fast arithmetic of the traversal, variant 0 or 2)
+        bool ok = world == 0 ? (g_variant == 0 || g_variant == 2 || g_variant == 3 || g_variant == 8) : (g_variant == 0 || g_variant == 2);
+        if (world == 1) {
+            ok = ok && scene->bvh->coords_not_tiny;
+            for (int k = 0; k < 3; ++k) {
+                const float o = camera->origin[k];
+                ok = ok && std::isfinite(o) && fabsf(o) <= 274877906944.0f && (o == 0.0f || fabsf(o) >= 1.3877787807814457e-17f);
+            }
+        }
+        if (ok) {
+            mat_view.material_of = world == 1 ? scene->bvh->d_material_slots : scene->d_material_of;
+            mat_view.materials = static_cast<const crt::MaterialPOD*>(scene->d_materials);
+            materials = &mat_view;
+            generic = false;
+        }
+    }
     int kernel_variant = 0;
     if (g_variant == 0 || g_variant == 2) kernel_variant = tiled_ok ? 1 : 0;
     else if (g_variant == 3) kernel_variant = tiled_ok ? 2 : 0;
@@ -921,7 +944,10 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         HIP_TRY(crt::launch_render_generic(p, t ? t->d_base_slots : scene->d_base, t ? t->d_shade_n_slots : scene->d_shade_n,
                                            t ? t->d_material_slots : scene->d_material_of, scene->d_materials, scene->n_tris,
                                            t ? t->d_nodes : nullptr, t ? t->n_nodes : 0, rot, rng->d_state, d_rgb, world == 1, fast,
-                                           shader, max_depth, force_mode, stream));
+                                           shader, max_depth, force_mode, stream,
+                                           // pair records for the incoherent secondary rays of `shade`; primary rays of one tile walk the
+                                           // same nodes and are a little faster over the skip links (variant 9: skip links everywhere)
+                                           (t && shader == CRT_SHADER_SHADE && g_variant != 9) ? t->d_pairs : nullptr, t ? t->d_partner : nullptr));
         cx.ev_has_mid = false;
         if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
         cx.ev_valid = timing;
@@ -945,7 +971,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
             HIP_TRY(crt::launch_frame_prepass(scene->bvh->d_base_slots, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
             HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, 1, &cx.w,
                                        cx.n_cus, true, g_d_stats, timing ? cx.ev_mid : nullptr, &cx.cache_bvh, true, stream,
-                                       static_cast<const crt::BvhTiles*>(scene->bvh->d_tiles_view), g_variant == 7));
+                                       static_cast<const crt::BvhTiles*>(scene->bvh->d_tiles_view), g_variant == 7, materials));
             cx.ev_has_mid = true;
             if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
             cx.ev_valid = timing;
@@ -970,7 +996,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->d_shade_n, rng->d_state,
                                d_rgb, kernel_variant, kernel_variant ? &cx.w : nullptr, cx.n_cus,
                                scene->tiled_safe && cam_ok, g_d_stats, (kernel_variant && timing) ? cx.ev_mid : nullptr, &cx.cache,
-                               kernel_variant != 0, stream));
+                               kernel_variant != 0, stream, nullptr, false, materials));
     cx.ev_has_mid = kernel_variant != 0;
     if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
     cx.ev_valid = timing;

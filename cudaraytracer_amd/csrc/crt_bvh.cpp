@@ -174,6 +174,7 @@ struct Builder {
 
 crt_bvh::~crt_bvh() {
     if (d_nodes) (void)hipFree(d_nodes);
+    if (d_pairs) (void)hipFree(d_pairs);
     if (d_base_slots) (void)hipFree(d_base_slots);
     if (d_shade_n_slots) (void)hipFree(d_shade_n_slots);
     if (d_idx_slots) (void)hipFree(d_idx_slots);
@@ -275,6 +276,29 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
             ++ord;
         }
     }
+    // pair records (crt_bvh_kernels.hpp: bvh_walk_pairs): one per inner node, preorder over the inner nodes; the references are
+    // static, the boxes are copied from the flat nodes on the device (after this upload and after every refit)
+    std::vector<float4> pairs;
+    if (b.max_depth + 1 <= crt::kPairStackDepth) {   // one stack entry per level (bvh_walk_pairs)
+        std::vector<int> pair_of((size_t)t->n_nodes, -1);
+        int n_inner = 0;
+        for (int i = 0; i < t->n_nodes; ++i)
+            if (b.nodes[i].count == 0) pair_of[i] = n_inner++;
+        pairs.assign((size_t)4 * n_inner, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        auto ref_of = [&](int node) {
+            const HostNode& nd = b.nodes[node];
+            return nd.count ? (int)(0x80000000u | ((unsigned)nd.count << 24) | (unsigned)nd.first) : pair_of[node];
+        };
+        for (int i = 0; i < t->n_nodes; ++i) {
+            if (b.nodes[i].count != 0) continue;
+            const int l = i + 1, r = b.nodes[l].skip;   // the left child follows its parent; its skip link is the right child
+            const int refs[4] = {ref_of(l), ref_of(r), l, r};
+            float4 p3;
+            memcpy(&p3, refs, sizeof p3);
+            pairs[(size_t)4 * pair_of[i] + 3] = p3;
+        }
+        t->n_pairs = n_inner;
+    }
     std::vector<int> level_nodes;
     t->level_offset.assign(1, 0);
     for (const std::vector<int>& lv : levels) {
@@ -307,6 +331,12 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
     if (e == hipSuccess) e = hipMemcpy(t->d_shade_n_slots, shade_slots.data(), shade_slots.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->d_idx_slots, idx_slots.data(), idx_slots.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->d_level_nodes, level_nodes.data(), level_nodes.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess && t->n_pairs > 0) {
+        e = hipMalloc(&t->d_pairs, pairs.size() * sizeof(float4));
+        if (e == hipSuccess) e = hipMemcpy(t->d_pairs, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = crt::launch_bvh_pairs(t->d_nodes, t->d_pairs, t->n_pairs, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
     if (e == hipSuccess) e = hipMalloc(&t->d_partner, partner.size() * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&t->d_slot_leaf, slot_leaf.size() * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&t->d_anc, anc.size() * sizeof(int));
@@ -346,6 +376,7 @@ int crt_scene_refit_bvh(crt_scene* s, void* stream_) {
         const int at = t->level_offset[level], cnt = t->level_offset[level + 1] - at;
         HIP_TRY(crt::launch_bvh_refit_level(t->d_nodes, t->d_level_nodes + at, cnt, t->d_base_slots, t->rot, (hipStream_t)stream_));
     }
+    HIP_TRY(crt::launch_bvh_pairs(t->d_nodes, t->d_pairs, t->n_pairs, (hipStream_t)stream_));   // the pair records carry copies of the boxes
     return CRT_OK;
 }
 

@@ -37,7 +37,15 @@ struct BvhView {
     const float4* nodes;
     int n_nodes;
     float rot[9];   // rows of rotate(., vec3(0)) as the reference computes them (host, crt_bvh.cpp)
+    // pair records (bvh_walk_pairs): one per INNER node, preorder over the inner nodes, 4 float4 = 64 B:
+    //   p0 = (L.min.xyz, L.max.x)  p1 = (L.max.yz, R.min.xy)  p2 = (R.min.z, R.max.xyz)  p3 = (refL, refR, flatL, flatR) as int bits
+    //   ref: child is a leaf ? 0x80000000 | count << 24 | first slot : the child's pair index;  flat: the child's node index
+    // null: the walks below use `nodes` only.
+    const float4* pairs = nullptr;
+    const int* partner = nullptr;   // BvhTiles::partner: the tie order as one key (larger wins among equal t)
 };
+
+// kPairStackDepth (crt_device.hpp): pending right children per lane (LDS); deeper trees take the skip-link walk
 
 __device__ __forceinline__ V3 rot0(const float* m, V3 v) {   // vec3.h:215: ((origin * rotate_k).sum()) = (x*a + y*b) + z*c
     return V3{(v.x * m[0] + v.y * m[1]) + v.z * m[2], (v.x * m[3] + v.y * m[4]) + v.z * m[5],
@@ -101,9 +109,14 @@ __device__ __forceinline__ bool box_hit_fast(float4 n0, float4 n1, V3 o, V3 d, V
 // per-frame exact records do not apply.
 template <bool FAST>
 __device__ __forceinline__ bool tri_hit_base(const float* __restrict__ b, V3 o, V3 d, float& t_out) {
-    if (d.x * b[9] + d.y * b[10] + d.z * b[11] < 0.0f) return false;          // triangle.h:61
-    const float e1x = b[3] - b[0], e1y = b[4] - b[1], e1z = b[5] - b[2];      // triangle.h:69
-    const float e2x = b[6] - b[0], e2y = b[7] - b[1], e2z = b[8] - b[2];      // triangle.h:70
+    // the 48-B record as three 16-B loads (records start on 16-B boundaries: 12 floats each from a hipMalloc base): per-lane
+    // records of incoherent rays cost one memory instruction per LOAD whatever its width — twelve dword loads were the
+    // largest item of a secondary ray's traversal
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(b);
+    const float4 ba = b4[0], bb = b4[1], bc = b4[2];   // v0.xyz v1.x | v1.yz v2.xy | v2.z n.xyz
+    if (d.x * bc.y + d.y * bc.z + d.z * bc.w < 0.0f) return false;           // triangle.h:61
+    const float e1x = ba.w - ba.x, e1y = bb.x - ba.y, e1z = bb.y - ba.z;      // triangle.h:69
+    const float e2x = bb.z - ba.x, e2y = bb.w - ba.y, e2z = bc.x - ba.z;      // triangle.h:70
     const float hx = (d.y * e2z - d.z * e2y);                                 // triangle.h:71-72
     const float hy = (-(d.x * e2z - d.z * e2x));
     const float hz = (d.x * e2y - d.y * e2x);
@@ -111,7 +124,7 @@ __device__ __forceinline__ bool tri_hit_base(const float* __restrict__ b, V3 o, 
     if (a > -kTriEpsilon && a < kTriEpsilon) return false;                    // triangle.h:77
     const float f = FAST ? ((fabsf(a) >= 7.888609052210118e-31f && fabsf(a) <= 1.2676506002282294e30f) ? reciprocal<true>(a) : 1.0f / a)
                          : 1.0f / a;                                          // triangle.h:80 (fast form valid for 2^-100..2^100)
-    const float sx = o.x - b[0], sy = o.y - b[1], sz = o.z - b[2];            // triangle.h:81
+    const float sx = o.x - ba.x, sy = o.y - ba.y, sz = o.z - ba.z;            // triangle.h:81
     const float u = f * (sx * hx + sy * hy + sz * hz);                        // triangle.h:82
     if (u < 0.0f || u > 1.0f) return false;                                   // triangle.h:84
     const float qx = (sy * e1z - sz * e1y);                                   // triangle.h:87
@@ -186,6 +199,108 @@ __device__ __forceinline__ void bvh_walk_fast(const BvhView& b, const float* __r
     }
 }
 
+// The hot loop over PAIR records.  The skip-link walk above pays one dependent 32-B load per VISITED node — and the
+// reference's rule visits both children of every node whose box is hit (bvh.h:160-190), 200 nodes for a typical ray of
+// the 100 000-triangle mesh, box hit or not.  Here a hit inner node's record holds the boxes of BOTH children: one 64-B
+// load, two slab tests, and only children that ARE hit are followed — half as many dependent loads, none for a child
+// whose box is missed.  The set of leaves whose triangles are tested is the same (a leaf is tested iff its box and the
+// boxes of all its ancestors are hit), each with the same direction, so the result is the same provided the merge rule
+// is applied as a key instead of in preorder: smallest t; among equal t the larger partner[slot] (= the later leaf,
+// and inside a leaf the first triangle: BvhTiles::partner).  A right child that waits while the left subtree is
+// walked sits on a per-lane stack in LDS (stack[level * stack_stride]).
+// Direction chains that are not at a fixed point by c3.  Camera rays of the reference camera almost always are (c4 == c3
+// for 99.98 %), arbitrary directions are not: 1 % of the scattered rays of `shade` have c4 != c3 — a third of them reach the
+// fixed point one step later (c5 == c4), half sit in a 2-cycle (c5 == c3) — so half of all wavefronts of secondary rays
+// held such a lane and the whole wavefront took the general loop (IEEE divisions, chain element by iteration: 5x the
+// time).  The pair walk therefore carries c3 AND c4 with their reciprocals and picks by depth:
+//     k <= 1: c1    k == 2: c2    k == 3: c3    k >= 4: cyc && (k odd) ? c3 : c4        (chain_at's rule for modes 0 and 1)
+// which serves every lane except those whose chain does neither by c5 (0.1 % of rays: they walk alone afterwards).
+struct PairDirs {
+    V3 c2, c3, c4, y2, y3, y4;
+    bool cyc;     // 2-cycle c3, c4, c3, c4, ... (chain_at mode 1); otherwise c_k = c4 for k >= 4
+};
+__device__ __forceinline__ bool pair_uses_c3(const PairDirs& pd, int k) {   // k >= 3
+    return k == 3 || (pd.cyc && (k & 1));
+}
+
+template <bool PRIMARY>
+__device__ __forceinline__ void pair_tri(const BvhView& b, const float* __restrict__ rec, int slot, V3 o, V3 dt, float& best_t, int& best_slot,
+                                         V3& dir_used) {
+    float t;
+    if (tri_hit_lane<true, PRIMARY>(rec, slot, o, dt, t) && t < FLT_MAX) {   // hitable_list.h:84 against t_max = FLT_MAX: NaN and +inf never pass
+        if (best_slot < 0 || t < best_t || (t == best_t && b.partner[slot] > b.partner[best_slot])) {
+            best_t = t;
+            best_slot = slot;
+            dir_used = dt;
+        }
+    }
+}
+template <bool PRIMARY>
+__device__ __forceinline__ void pair_leaf(const BvhView& b, const float* __restrict__ rec, int ref, V3 o, V3 dt, float& best_t, int& best_slot,
+                                          V3& dir_used) {
+    const int first = ref & 0xffffff, count = (ref >> 24) & 3;   // 1 or 2 triangles (bvh.h:95-109)
+    pair_tri<PRIMARY>(b, rec, first, o, dt, best_t, best_slot, dir_used);
+    if (count == 2) pair_tri<PRIMARY>(b, rec, first + 1, o, dt, best_t, best_slot, dir_used);
+}
+
+// `take`: this lane walks here (its chain is served by PairDirs and its components are ordinary); the others keep their result.
+// Depth first, one record per trip; a hit inner child that has to wait sits on the lane's stack (at most one entry per
+// level).  Measured and dropped: two records per trip (the stack top together with the current node) — the LDS of a
+// stack with two entries per level halves the resident blocks of the generic kernel, and that costs more (shade 19.8 ->
+// 26.9 ms) than the second record in flight gains.  Returns false for a lane that ran out of stack (the caller walks it
+// again with the general loop; the host only builds pair records for trees that fit).
+template <bool PRIMARY = true>
+__device__ __forceinline__ bool bvh_walk_pairs(const BvhView& b, const float* __restrict__ rec, V3 o, V3 c1, const PairDirs& pd, bool take,
+                                               int* __restrict__ stack, int stack_stride, float& best_t, int& best_slot, V3& dir_used) {
+    bool alive = take, overflow = false;
+    {   // the root: its own box sees c1 (depth 0, k = 1)
+        const float4 n0 = b.nodes[0], n1 = b.nodes[1];
+        const V3 y1 = V3{reciprocal<true>(c1.x), reciprocal<true>(c1.y), reciprocal<true>(c1.z)};
+        alive = alive && box_hit_fast(n0, n1, o, c1, y1);
+        const int info = __float_as_int(n1.w);
+        if (((info >> 24) & 3) != 0) {   // a one-leaf tree (wave-uniform: the same node for every lane): its triangles see k = 3
+            if (alive) pair_leaf<PRIMARY>(b, rec, (int)(0x80000000u | (unsigned)(info & 0x3ffffff)), o, pd.c3, best_t, best_slot, dir_used);
+            return true;
+        }
+    }
+    int cur = 0, sp = 0, depth = 0;   // depth of the pair's node: its children's boxes see k = depth + 2, a leaf child's triangles k = depth + 4
+    // ONE loop with a wave-uniform condition; a lane that has run out of nodes is masked, the others go on.  (Written as a
+    // per-lane `for (;;)` with break / pop branches the compiler nests the loops, and a lane that needs to pop waits for
+    // every other lane of the wavefront to reach a dead end: 2x slower than the skip links, measured.)
+    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+        if (alive) {
+            const float4* __restrict__ pr = b.pairs + 4 * (size_t)cur;
+            const float4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+            const int k = depth + 2;
+            const bool box3 = pair_uses_c3(pd, k), tri3 = pd.cyc && (k & 1);   // k + 2 >= 4 has k's parity
+            const V3 d = (k == 2) ? pd.c2 : (box3 ? pd.c3 : pd.c4), y = (k == 2) ? pd.y2 : (box3 ? pd.y3 : pd.y4);
+            const V3 dt = tri3 ? pd.c3 : pd.c4;
+            const bool hit_l = box_hit_fast(p0, make_float4(p1.x, p1.y, 0.0f, 0.0f), o, d, y);
+            const bool hit_r = box_hit_fast(make_float4(p1.z, p1.w, p2.x, p2.y), make_float4(p2.z, p2.w, 0.0f, 0.0f), o, d, y);
+            const int ref_l = __float_as_int(p3.x), ref_r = __float_as_int(p3.y);
+            if (hit_l && ref_l < 0) pair_leaf<PRIMARY>(b, rec, ref_l, o, dt, best_t, best_slot, dir_used);
+            if (hit_r && ref_r < 0) pair_leaf<PRIMARY>(b, rec, ref_r, o, dt, best_t, best_slot, dir_used);
+            const bool go_l = hit_l && ref_l >= 0, go_r = hit_r && ref_r >= 0;
+            ++depth;
+            if (go_l && go_r) {
+                overflow = sp >= kPairStackDepth;
+                if (!overflow) stack[sp * stack_stride] = ref_r | (depth << 26);
+                ++sp;
+            }
+            int next = go_l ? ref_l : (go_r ? ref_r : -1);
+            if (next < 0 && sp > 0) {
+                --sp;
+                const int e = stack[sp * stack_stride];
+                next = e & 0x3ffffff;
+                depth = (e >> 26) & 31;
+            }
+            alive = next >= 0 && !overflow;
+            cur = next;
+        }
+    }
+    return !overflow;
+}
+
 // General loop: chain element by depth, literal arithmetic.  mode: 0 = c_k is c4 for k > 4 (fixed
 // point reached by c4 at the latest), 1 = 2-cycle (c5 == c3: odd k -> c3, even k -> c4), 2 = neither:
 // iterate F from c4.
@@ -228,32 +343,59 @@ __device__ __forceinline__ void bvh_walk_general(const BvhView& b, const float* 
 // slot-ordered base records.  dir_used: direction of the winning triangle's test (for rec.p).
 template <bool FAST, bool PRIMARY = true>
 __device__ __forceinline__ void bvh_trace(const BvhView& b, const float* __restrict__ rec, V3 o, V3 d1, int force_mode,
-                                          float& best_t, int& best_slot, V3& dir_used) {
+                                          float& best_t, int& best_slot, V3& dir_used, int* __restrict__ stack = nullptr,
+                                          int stack_stride = 0) {
     const V3 c1 = rot0_exact(b.rot, d1);
     const V3 c2 = chain_next<FAST>(b.rot, c1);
     const V3 c3 = chain_next<FAST>(b.rot, c2);
     const V3 c4 = chain_next<FAST>(b.rot, c3);
     best_t = FLT_MAX;
     best_slot = -1;
-    bool hot = FAST && force_mode == 0 && same_bits(c4, c3);
-    if (hot) {   // ordinary: every component of the three directions is at least 2^-40 in magnitude (and finite)
+    const bool fixed3 = same_bits(c4, c3);
+    // ordinary: every component of the directions is at least 2^-40 in magnitude (and finite)
+    bool ordinary = FAST && force_mode == 0;
+    if (ordinary) {
         const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
                                fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
-        hot = lo >= 9.094947017729282e-13f;
+        ordinary = lo >= 9.094947017729282e-13f && fminf(fminf(fabsf(c4.x), fabsf(c4.y)), fabsf(c4.z)) >= 9.094947017729282e-13f;
         if (!PRIMARY) {   // any origin: a coordinate difference below the fast division's range needs a tiny nonzero component
             const float ax = fabsf(o.x), ay = fabsf(o.y), az = fabsf(o.z);
-            hot = hot && (ax == 0.0f || ax >= 1.3877787807814457e-17f) && (ay == 0.0f || ay >= 1.3877787807814457e-17f) &&
-                  (az == 0.0f || az >= 1.3877787807814457e-17f) && fmaxf(fmaxf(ax, ay), az) <= 1099511627776.0f;
+            ordinary = ordinary && (ax == 0.0f || ax >= 1.3877787807814457e-17f) && (ay == 0.0f || ay >= 1.3877787807814457e-17f) &&
+                       (az == 0.0f || az >= 1.3877787807814457e-17f) && fmaxf(fmaxf(ax, ay), az) <= 1099511627776.0f;
         }
     }
     dir_used = c3;
-    if (__builtin_amdgcn_ballot_w64(!hot) == 0ull) {
+    const bool pairs = stack != nullptr && b.pairs != nullptr;
+    if (!pairs && __builtin_amdgcn_ballot_w64(!(ordinary && fixed3)) == 0ull) {   // skip links, every lane on the hot chain
         bvh_walk_fast<PRIMARY>(b, rec, o, c1, c2, c3, best_t, best_slot);
         return;
     }
-    const V3 c5 = chain_next<FAST>(b.rot, c4);
-    int mode = same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2);
+    // some lane is off the hot chain (or the pair walk serves them anyway): one more chain element decides how it goes on
+    V3 c5 = c4;
+    int mode = 0;
+    if (__builtin_amdgcn_ballot_w64(!fixed3) != 0ull || force_mode != 0) {
+        c5 = chain_next<FAST>(b.rot, c4);
+        mode = fixed3 ? 0 : (same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2));
+    }
     if (force_mode == 2) mode = 2;   // test hook: every lane iterates F from c4 (must give the same pixels)
+    if (pairs) {
+        PairDirs pd;
+        pd.c2 = c2; pd.c3 = c3; pd.c4 = c4;
+        pd.y2 = V3{reciprocal<true>(c2.x), reciprocal<true>(c2.y), reciprocal<true>(c2.z)};
+        pd.y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
+        pd.y4 = V3{reciprocal<true>(c4.x), reciprocal<true>(c4.y), reciprocal<true>(c4.z)};
+        pd.cyc = mode == 1;
+        bool take = ordinary && mode != 2;
+        if (!bvh_walk_pairs<PRIMARY>(b, rec, o, c1, pd, take, stack, stack_stride, best_t, best_slot, dir_used)) {
+            take = false;          // ran out of stack: start over below
+            best_t = FLT_MAX;
+            best_slot = -1;
+        }
+        if (__builtin_amdgcn_ballot_w64(!take) != 0ull) {   // the few lanes the pair walk cannot serve: alone, the literal way
+            if (!take) bvh_walk_general<FAST, PRIMARY>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot, dir_used);
+        }
+        return;
+    }
     bvh_walk_general<FAST, PRIMARY>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot, dir_used);
 }
 
@@ -509,7 +651,8 @@ render_bvh_kernel(RenderParams p, BvhView b, const float* __restrict__ rec, cons
     const bool valid = x < p.nx && ly < p.row_count;                  // render.h:109
     if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
     const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-    // lanes off the image replay a valid pixel (unstored): the traversal votes need whole wavefronts
+    // lanes off the image replay a valid pixel (unstored): the traversal votes need whole wavefronts.  Primary rays of one
+    // tile walk the same nodes: the skip-link walk (no pair records: measured 2.5 against 2.7 ms per 4-spp C3 frame)
     render_pixel<FAST, false, false>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, valid,
                                      [&](V3 d1, V3, float& closest, int& hit_idx) {
         V3 dir_used;
@@ -592,6 +735,26 @@ bvh_refit_level_kernel(float4* __restrict__ nodes, const int* __restrict__ level
     }
     nodes[2 * (size_t)i] = make_float4(box.mn[0], box.mn[1], box.mn[2], box.mx[0]);
     nodes[2 * (size_t)i + 1] = make_float4(box.mx[1], box.mx[2], n1.z, n1.w);
+}
+
+// Pair records from the flat nodes (after the build's upload and after every refit): lane = inner node; the boxes of its two
+// children are copied next to each other (bvh_walk_pairs); the references p3 are static (host, crt_bvh.cpp).
+__global__ void __launch_bounds__(256)
+bvh_pairs_kernel(const float4* __restrict__ nodes, float4* __restrict__ pairs, int n_pairs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pairs) return;
+    const float4 p3 = pairs[4 * (size_t)j + 3];
+    const int l = __float_as_int(p3.z), r = __float_as_int(p3.w);
+    const float4 l0 = nodes[2 * (size_t)l], l1 = nodes[2 * (size_t)l + 1], r0 = nodes[2 * (size_t)r], r1 = nodes[2 * (size_t)r + 1];
+    pairs[4 * (size_t)j + 0] = l0;                                          // L.min.xyz, L.max.x
+    pairs[4 * (size_t)j + 1] = make_float4(l1.x, l1.y, r0.x, r0.y);         // L.max.yz, R.min.xy
+    pairs[4 * (size_t)j + 2] = make_float4(r0.z, r0.w, r1.x, r1.y);         // R.min.z, R.max.xyz
+}
+
+hipError_t launch_bvh_pairs(const float4* d_nodes, float4* d_pairs, int n_pairs, hipStream_t stream) {
+    if (n_pairs <= 0 || d_pairs == nullptr) return hipSuccess;
+    hipLaunchKernelGGL(bvh_pairs_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, d_nodes, d_pairs, n_pairs);
+    return hipGetLastError();
 }
 
 hipError_t launch_bvh_refit_level(float4* d_nodes, const int* d_level_nodes, int n_level, const float* d_base_slots,

@@ -125,12 +125,22 @@ struct LaunchCache {
     const void* fn = nullptr;
     int resident = 0;
 };
+// crt_material (include/crt.h) as the kernels read it, and the per-triangle material view of a launch
+struct MaterialPOD {
+    int kind;          // 0 Lambertian, 1 Metal, 2 Dielectric, 3 DiffuseLight
+    float albedo[3];
+    float param;       // Metal: fuzz (clamped to 1 like the ctor); Dielectric: ref_idx
+};
+struct MatView {
+    const int* material_of = nullptr;        // per triangle (list order) or per slot (BVH world); null = all 0
+    const MaterialPOD* materials = nullptr;  // null: the scene's single Lambertian (RenderParams::albedo)
+};
 struct BvhTiles;
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
                          hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream,
-                         const BvhTiles* d_bvh_tiles = nullptr, bool bvh_force_general = false);
+                         const BvhTiles* d_bvh_tiles = nullptr, bool bvh_force_general = false, const MatView* materials = nullptr);
 // The per-frame prepass of the tiled variant in ONE launch: exact records (tri_prepass) + classification
 // records (cls_prepass) + zeroing of this frame's binning scratch (w.tile_count, w.counters);
 // launch_render is then called with prezeroed = true.
@@ -162,6 +172,9 @@ constexpr int kStatsTotalWords = kStatsSampleLog + 2 * kStatsSampleBlocks * kSta
 hipError_t launch_render_bvh(const RenderParams& p, const float4* d_nodes, int n_nodes, const float rot[9], const float* d_rec,
                              const float* d_shade_n, uint32_t* d_state, float* d_rgb, bool fast, int force_mode,
                              hipStream_t stream);
+// pair records of the tree (crt_bvh_kernels.hpp: bvh_walk_pairs): boxes refreshed from the flat nodes
+hipError_t launch_bvh_pairs(const float4* d_nodes, float4* d_pairs, int n_pairs, hipStream_t stream);
+constexpr int kPairStackDepth = 24;   // entries of the per-lane stack of bvh_walk_pairs (one per tree level); deeper trees keep the skip-link walk
 // The generic render kernel (crt_shade_kernels.hpp): shader 0 LambertShade, 1 shade (recursive, depth
 // <= max_depth < kMaxShadeDepth), 2 shade_normal; world = list (d_nodes null) or BVH; per-triangle
 // materials (d_materials: array of {int kind; float albedo[3]; float param}).  d_base / d_shade_n /
@@ -170,7 +183,7 @@ constexpr int kMaxShadeDepth = 31;
 hipError_t launch_render_generic(const RenderParams& p, const float* d_base, const float* d_shade_n, const int* d_material_of,
                                  const void* d_materials, int n_tris, const float4* d_nodes, int n_nodes, const float rot[9],
                                  uint32_t* d_state, float* d_rgb, bool bvh, bool fast, int shader, int max_depth, int force_mode,
-                                 hipStream_t stream);
+                                 hipStream_t stream, const float4* d_pairs = nullptr, const int* d_partner = nullptr);
 // What the tiled kernels need of the tree to serve the BVH world's PRIMARY rays:
 // a triangle is hit through the tree iff it passes Triangle::collision_detection AND the boxes of its
 // leaf and of all the leaf's ancestors pass AABB::hit — the tile lists (a superset of the first

@@ -530,11 +530,14 @@ __device__ __forceinline__ float in_vgpr(float x) {
 // SPEC: `traverse` takes a fifth argument, a functor that runs the hit branch's rejection draws on a COPY of the stream
 // (the master wave of a shared tile calls it while the other waves trace); a lane that turns out to have hit adopts
 // the copy, a lane that missed keeps its stream as it was — the draws a pixel consumes are the same either way.
-template <bool FASTDIV = false, bool SKYONLY = false, bool WANT_D2 = true, bool SPEC = false, class Traverse>
+// MAT: LambertShade with a Material* per triangle (crt_scene_set_materials; render.h:75-83 with material.h:57-161): what the hit
+// triangle's material draws and returns as attenuation / emitted; otherwise the scene's one Lambertian.
+template <bool FASTDIV = false, bool SKYONLY = false, bool WANT_D2 = true, bool SPEC = false, bool MAT = false, class Traverse>
 __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int ly,
                                              const float* __restrict__ shade_n,
                                              uint32_t* __restrict__ state, float* __restrict__ rgb,
-                                             bool store, Traverse traverse) {
+                                             bool store, Traverse traverse, MatView mv = MatView{}) {
+    static_assert(!(SPEC && MAT), "the speculative hit-branch draws assume one Lambertian: what is drawn depends on the hit material");
     const int y = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
     const long long pixel_index = (long long)y * p.nx + x;             // render.h:111 (global)
     const long long si = (long long)ly * p.nx + x;                     // element of this launch's states
@@ -622,7 +625,29 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
             // Lambertian::scatter -> random_in_unit_sphere: only the draws matter (material.h:11-19,66)
             const float* sn = shade_n + (size_t)hit_idx * 3;           // normal after both rotate() calls
             const float snx = sn[0], sny = sn[1], snz = sn[2];         // requested before the draws: the latency overlaps them
-            if constexpr (SPEC) {
+            float ax = p.albedo[0], ay = p.albedo[1], az = p.albedo[2], ex = 0.0f, ey = 0.0f, ez = 0.0f;
+            if constexpr (MAT) {
+                // mat_ptr->scatter(...) for its draws and `attenuation`, mat_ptr->emitted (render.h:78-79):
+                //   Lambertian / Metal: random_in_unit_sphere (material.h:66,87), attenuation = albedo
+                //   Dielectric: ONE uniform (material.h:134), attenuation = (1, 1, 1)
+                //   DiffuseLight: no draw, attenuation stays unwritten (defined as 0, as the oracle), emitted = the light's colour
+                const MaterialPOD m = mv.materials[mv.material_of ? mv.material_of[hit_idx] : 0];
+                if (m.kind <= 1) {
+                    float sxr, syr, szr;
+                    do {
+                        sxr = xw_uniform_2m1(rs);
+                        syr = xw_uniform_2m1(rs);
+                        szr = xw_uniform_2m1(rs);
+                    } while (sxr * sxr + syr * syr + szr * szr >= 1.0f);
+                    ax = m.albedo[0]; ay = m.albedo[1]; az = m.albedo[2];
+                } else if (m.kind == 2) {
+                    (void)xw_uniform(rs);
+                    ax = 1.0f; ay = 1.0f; az = 1.0f;
+                } else {
+                    ax = 0.0f; ay = 0.0f; az = 0.0f;
+                    ex = m.albedo[0]; ey = m.albedo[1]; ez = m.albedo[2];
+                }
+            } else if constexpr (SPEC) {
                 rs = rs_hit;
             } else {
                 float sxr, syr, szr;
@@ -635,9 +660,9 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
             float t = d0.x * snx + d0.y * sny + d0.z * snz;            // dot(r.direction(), rec.normal)
             if (t < 0.0f) t = 0.0f;
             // attenuation * t * backgroundSky(...) * 0.2 + emitted
-            colx += 0.2f * ((t * p.albedo[0]) * sky.x) + 0.0f;
-            coly += 0.2f * ((t * p.albedo[1]) * sky.y) + 0.0f;
-            colz += 0.2f * ((t * p.albedo[2]) * sky.z) + 0.0f;
+            colx += 0.2f * ((t * ax) * sky.x) + ex;
+            coly += 0.2f * ((t * ay) * sky.y) + ey;
+            colz += 0.2f * ((t * az) * sky.z) + ez;
         } else {
             colx += sky.x;                                             // render.h:85
             coly += sky.y;
@@ -1439,12 +1464,12 @@ __device__ __forceinline__ void trace_pairs(StageArea& area, const int* ent, con
 // than 32 survivors (or without a list) and wave-samples off the hot direction chain take the
 // tree itself (bvh_trace).  Heavy tiles keep the 8-wave scheme: the master wave publishes c3, merges the slices' keys and
 // checks the winner's chain.
-template <bool VREC, int OCC, int WAVES, bool BVH = false>
+template <bool VREC, int OCC, int WAVES, bool BVH = false, bool MAT = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
                    TiledWork w, unsigned long long* __restrict__ stats_in, int dbg_repeat_in, const BvhTiles* __restrict__ bvh,
-                   unsigned split_packed) {
+                   unsigned split_packed, MatView mv) {
     // diagnostics: stats_in[kStatsTimeline] != 0 selects the light-weight timeline (wave start/end times only), which
     // leaves the kernel's timing intact; otherwise the full counters (which roughly double the kernel time)
     const bool timeline = stats_in != nullptr && stats_in[kStatsTimeline] != 0ull;
@@ -1631,10 +1656,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 #pragma unroll
                     for (int k = 0; k < 9; ++k) view.rot[k] = bvh->rot[k];
                     const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-                    render_pixel<true, false, false>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                    render_pixel<true, false, false, false, MAT>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
                         V3 used;
                         bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
-                    });
+                    }, mv);
                 }
             } else if (BVH && wave == 0) {
                 // Master wave, BVH mode: publishes c3 (what the triangles see on the hot chain), merges the slices' keys,
@@ -1646,7 +1671,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 const int first_level = __builtin_amdgcn_readfirstlane(
                     tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[0], lane));
                 int tl_sample_bvh = 0;   // timeline mode: (slices done, chains checked) per sample of the first blocks' first tile
-                render_pixel<true, false, false>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                render_pixel<true, false, false, false, MAT>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     const V3 c1 = rot0_exact(bt.rot, d1);
                     const V3 c2 = chain_next<true>(bt.rot, c1);
                     const V3 c3 = chain_next<true>(bt.rot, c2);
@@ -1704,12 +1729,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         stats_in[kStatsSampleLog + (blockIdx.x * kStatsSampleSlots + tl_sample_bvh) * 2 + 1] = (unsigned long long)wall_clock64();   // winners' chains checked
                         ++tl_sample_bvh;
                     }
-                });
+                }, mv);
             } else if (wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
                 int tl_sample = 0;   // timeline mode: the first blocks log two time stamps per sample of their first shared tile
-                render_pixel<true, false, true, true>(p, x, ly, shade_n, state, rgb, lane_valid,
-                             [&](V3, V3 d2, float& closest, int& hit_idx, auto&& hit_branch_draws) {
+                render_pixel<true, false, true, !MAT, MAT>(p, x, ly, shade_n, state, rgb, lane_valid,
+                             [&](V3, V3 d2, float& closest, int& hit_idx, auto&&... hit_branch_draws) {
                     ray_d[0][lane] = d2.x;
                     ray_d[1][lane] = d2.y;
                     ray_d[2][lane] = d2.z;
@@ -1717,7 +1742,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     long long tc0 = 0, tc1 = 0, tc2 = 0;
                     if (stats) { tc0 = (long long)clock64(); tc_setup += tc0 - tc_prev; }
                     __syncthreads();   // B1
-                    hit_branch_draws();   // on a copy of the stream, while the other waves trace
+                    (hit_branch_draws(), ...);   // list world, one Lambertian: on a copy of the stream, while the other waves trace
                     if (timeline && blockIdx.x < (unsigned)kStatsSampleBlocks && lane == 0 && tl_sample < kStatsSampleSlots) {
                         stats_in[kStatsSampleLog + (blockIdx.x * kStatsSampleSlots + tl_sample) * 2 + 0] = (unsigned long long)wall_clock64();   // draws done
                     }
@@ -1730,7 +1755,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     }
                     const unsigned long long kbest = best_key[lane];
                     hit_idx = (kbest == ~0ull) ? -1 : (int)(unsigned)(kbest & 0xffffffffull);
-                });
+                }, mv);
                 if (stats && lane == 0) {   // master-wave time split: (merge+shade+next setup), own trace, wait for the slowest slice
                     atomicAdd(&stats[32], (unsigned long long)tc_setup);
                     atomicAdd(&stats[33], (unsigned long long)tc_trace);
@@ -1841,7 +1866,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
                 const int first_level = __builtin_amdgcn_readfirstlane(
                     tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[wave], lane));
-                render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     const V3 c1 = rot0_exact(view.rot, d1);
                     const V3 c2 = chain_next<true>(view.rot, c1);
                     const V3 c3 = chain_next<true>(view.rot, c2);
@@ -1876,14 +1901,14 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
                     }
                     closest = 0.0f;
-                });
+                }, mv);
                 continue;
             }
             if (!VREC || desc.y == kNoList) {   // no list (pool overflow): every sample walks the tree
-                render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     V3 used;
                     bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
-                });
+                }, mv);
                 continue;
             }
             if (cnt > 64) {
@@ -1914,7 +1939,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 for (int c = 0; c < 4; ++c)
                     q_c[c] = (c < n_chunks && lane < min(64, cnt - 64 * c))
                                  ? (int)(((unsigned)ent_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bt.partner[ent_c[c] & 0x7fffffff])) : 0;
-                render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     const V3 c1 = rot0_exact(view.rot, d1);
                     const V3 c2 = chain_next<true>(view.rot, c1);
                     const V3 c3 = chain_next<true>(view.rot, c2);
@@ -1981,7 +2006,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                                             if ((k >> 6) == c && ((k >> 5) & 1) == h) ex[c][h] |= 1u << (k & 31);
                                 }
                     }
-                });
+                }, mv);
                 continue;
             }
             stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, cnt, lane, px,
@@ -2022,7 +2047,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             if (!store) cand.lo = cand.hi = 0u;
             unsigned bp = 0xffffffffu;
             if (WAVES <= 8) bp = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
-            render_pixel<true, false, false>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
+            render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                 const V3 c1 = rot0_exact(view.rot, d1);
                 const V3 c2 = chain_next<true>(view.rot, c1);
                 const V3 c3 = chain_next<true>(view.rot, c2);
@@ -2119,7 +2144,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         else excl_hi |= 1u << (kw - 32);
                     }
                 }
-            });
+            }, mv);
             continue;
         }
         if (VREC && cnt > 0)   // all 64 lanes, before any lane leaves: lanes off the image classify a valid pixel
@@ -2158,7 +2183,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         if (cnt == 0) {   // background only (most tiles of a typical frame)
             if (x < p.nx && ly < p.row_count) render_sky_pixel(p, x, ly, state, rgb);
         } else if (pair_mode) {   // all 64 lanes stay active (ds_bpermute reads lanes); off-image lanes replay a valid pixel, unstored
-            render_pixel<true>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, x < p.nx && ly < p.row_count,
+            render_pixel<true, false, true, false, MAT>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, x < p.nx && ly < p.row_count,
                          [&](V3, V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 lkey[wave][lane] = ~0ull;
@@ -2176,9 +2201,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 hit_idx = (kb == ~0ull) ? -1 : (int)(unsigned)(kb & 0xffffffffull);
                 closest = 0.0f;   // not used after the traversal
               }
-            });
+            }, mv);
         } else if (x < p.nx && ly < p.row_count) {
-            render_pixel<true>(p, x, ly, shade_n, state, rgb, true,
+            render_pixel<true, false, true, false, MAT>(p, x, ly, shade_n, state, rgb, true,
                          [&](V3, V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (VREC) {
@@ -2189,7 +2214,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     walk<true>(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
                 }
               }
-            });
+            }, mv);
         }
     }
     if (stats && lane == 0) {   // cycle accounting (diagnostics): heavy phase per block, light phase per wave
@@ -2382,7 +2407,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
                          hipEvent_t ev_mid, LaunchCache* cache, bool prezeroed, hipStream_t stream, const BvhTiles* d_bvh_tiles,
-                         bool bvh_force_general) {
+                         bool bvh_force_general, const MatView* materials) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     if (variant == 0 || d_cls == nullptr || work == nullptr) {
         dim3 block(256);
@@ -2415,7 +2440,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
 #endif
     using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int,
-                             const BvhTiles*, unsigned);
+                             const BvhTiles*, unsigned, MatView);
     // log2 of the number of row slabs a heavy tile of each weight class (> 768, 512, 384, 256, 192, 128, 96, 64, heavy) is dealt
     // out as (shade_tiles_kernel: sub-items).  Measured (profiles/r3_tiled/sweep_split_*.txt): splitting the heaviest tiles
     // x2 .. x8 changes neither the full frame nor the slowest rank of an 8-way split, on either C3 mesh — what bounds a
@@ -2450,8 +2475,11 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
 #define CRT_BVH_OCC 4   // the block's 62 KB of LDS allow two blocks per CU = 4 waves/SIMD; asked for 6, the compiler gives up on the
                         // target and takes 220 VGPRs = 2 waves/SIMD (C3 2.46 ms, C5 17.0); held to 128 VGPRs: 1.70 / 10.5 ms (sweep_bvh.txt)
 #endif
-        fn = shade_tiles_kernel<true, CRT_BVH_OCC, 8, true>;
+        fn = materials ? shade_tiles_kernel<true, CRT_BVH_OCC, 8, true, true> : shade_tiles_kernel<true, CRT_BVH_OCC, 8, true>;
         if (bvh_force_general) dbg_repeat = -77;
+    } else if (materials) {   // LambertShade with a material per triangle: the staged 8-wave kernel
+        group = 8;
+        fn = shade_tiles_kernel<true, 6, 8, false, true>;
     }
     // persistent blocks: exactly as many as are resident at once (block b starts with heavy item b);
     // the occupancy query is cached per launch context (device + stream), not per host thread
@@ -2474,7 +2502,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)n_blocks), dim3((unsigned)group * 64), 0, stream, p, d_rec, d_cls, n_pad, d_shade_n,
-                       d_state, d_rgb, w, d_stats, dbg_repeat, d_bvh_tiles, split_packed);
+                       d_state, d_rgb, w, d_stats, dbg_repeat, d_bvh_tiles, split_packed, materials ? *materials : MatView{});
     return hipGetLastError();
 }
 

@@ -22,11 +22,7 @@
 
 constexpr int kMaxDepthLevels = 32;   // shade(): max_depth + 1 levels of material indices per lane in LDS
 
-struct MaterialPOD {   // crt_material (include/crt.h)
-    int kind;          // 0 Lambertian, 1 Metal, 2 Dielectric, 3 DiffuseLight
-    float albedo[3];
-    float param;       // Metal: fuzz (clamped to 1 like the ctor); Dielectric: ref_idx
-};
+// MaterialPOD: crt_device.hpp
 
 struct ShadeScene {
     const float* base;            // n x 12 base records: list order (list world) or slot order (BVH world)
@@ -63,12 +59,12 @@ __device__ __forceinline__ void list_trace_any(const ShadeScene& sc, V3 o, V3 d1
 }
 
 template <bool FAST, bool BVH>
-__device__ __forceinline__ HitInfo trace_any(const ShadeScene& sc, const BvhView& b, V3 o, V3 d, int force_mode) {
+__device__ __forceinline__ HitInfo trace_any(const ShadeScene& sc, const BvhView& b, V3 o, V3 d, int force_mode, int* __restrict__ stack) {
     // Hitable::hit at the world level: ScaleRay normalises (transform.h:50-54)
     const V3 d1 = FAST ? unit_vector_fast(d) : unit_vector(d);
     HitInfo h;
     V3 used;
-    if (BVH) bvh_trace<FAST, false>(b, sc.base, o, d1, force_mode, h.t, h.idx, used);
+    if (BVH) bvh_trace<FAST, false>(b, sc.base, o, d1, force_mode, h.t, h.idx, used, stack, 256);
     else list_trace_any<FAST>(sc, o, d1, h.t, h.idx, used);
     if (h.idx >= 0) {
         h.p = V3{o.x + h.t * used.x, o.y + h.t * used.y, o.z + h.t * used.z};   // rec.p = r.point_at_t(rec.t), triangle.h:95
@@ -177,6 +173,8 @@ __global__ void __launch_bounds__(256)
 render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __restrict__ state, float* __restrict__ rgb,
                       int shader, int max_depth, int force_mode) {
     __shared__ unsigned short level_mat[kMaxDepthLevels][256];   // material indices (crt_scene_set_materials: at most 65 536 materials)
+    extern __shared__ int pair_stack[];   // bvh_walk_pairs: kPairStackDepth x 256 pending right children (launched with it only when the pair records are used)
+    int* const stack = (BVH && b.pairs != nullptr) ? &pair_stack[threadIdx.x] : nullptr;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int xr = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
@@ -223,7 +221,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
         }
         if (__builtin_amdgcn_ballot_w64(in_flight) == 0ull) break;
         if (in_flight) {
-            const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode);
+            const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode, stack);
             V3 L = V3{0.0f, 0.0f, 0.0f};
             bool done = true;
             if (shader == 1) {
@@ -297,7 +295,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
 hipError_t launch_render_generic(const RenderParams& p, const float* d_base, const float* d_shade_n, const int* d_material_of,
                                  const void* d_materials, int n_tris, const float4* d_nodes, int n_nodes, const float rot[9],
                                  uint32_t* d_state, float* d_rgb, bool bvh, bool fast, int shader, int max_depth, int force_mode,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, const float4* d_pairs, const int* d_partner) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     ShadeScene sc;
     sc.base = d_base; sc.shade_n = d_shade_n; sc.material_of = d_material_of;
@@ -305,10 +303,12 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
     sc.n_tris = n_tris;
     BvhView b;
     b.nodes = d_nodes; b.n_nodes = n_nodes;
+    b.pairs = d_pairs; b.partner = d_partner;
     for (int k = 0; k < 9; ++k) { sc.rot[k] = rot[k]; b.rot[k] = rot[k]; }
     dim3 block(256), grid((unsigned)((p.nx + 15) / 16), (unsigned)((p.row_count + 15) / 16));
     auto fn = bvh ? (fast ? render_generic_kernel<true, true> : render_generic_kernel<false, true>)
                   : (fast ? render_generic_kernel<true, false> : render_generic_kernel<false, false>);
-    hipLaunchKernelGGL(fn, grid, block, 0, stream, p, sc, b, d_state, d_rgb, shader, max_depth, force_mode);
+    const size_t lds = (bvh && d_pairs != nullptr) ? (size_t)kPairStackDepth * 256 * sizeof(int) : 0;
+    hipLaunchKernelGGL(fn, grid, block, lds, stream, p, sc, b, d_state, d_rgb, shader, max_depth, force_mode);
     return hipGetLastError();
 }

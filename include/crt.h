@@ -276,7 +276,8 @@ int crt_render_rows_ex(const crt_scene *scene, const crt_camera *camera, crt_rng
  * masks (A/B), 8 = tiled with a 16-record binning log (test hook for its overflow fallback); BVH world only: 1 = the per-ray tree walk instead of the tiled kernels, 5 = the walk's
  * general loop for every wavefront, 6 = the same with every direction chain iterated from its
  * fourth element, 7 = the tiled kernels with every lane on their general per-lane path (test hooks
- * for the rare paths).
+ * for the rare paths), 9 = crt_render_rows_ex with the recursive shader walks the skip links of the flat node array instead of the
+ * pair records (A/B).
  * All variants produce identical pixels.  Returns the previous value. */
 int crt_set_kernel_variant(int variant);
 

@@ -235,7 +235,7 @@ def assert_same_tree(scene, bvh):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 9])
 @pytest.mark.parametrize("name", sorted(BVH_GOLDEN))
 def test_gpu_bvh_matches_golden(gpu, golden_dir, name, variant):
     """Tree (boxes, structure, leaf order) and frame equal the oracle's: primary rays through the
@@ -265,7 +265,7 @@ def test_gpu_bvh_random_soup_matches_oracle(gpu, oracle, seed, ntri, nx, ny, spp
     states = oracle.fresh_states(nx, ny)
     bvh = oracle.Bvh(w, states)
     ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
-    for variant in (0, 1, 5, 6, 7):
+    for variant in (0, 1, 5, 6, 7, 9):
         (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
         assert_same_tree(scene, bvh)
         assert np.array_equal(bits(rgb), bits(ref)), variant
@@ -417,7 +417,7 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
     bvh = oracle.Bvh(w, states)
     ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
     after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
-    for variant in (0, 1, 7):
+    for variant in (0, 1, 7, 9):
         if kind == "stack" and variant == 0:
             api.tiled_stats(1)
         (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)

@@ -142,7 +142,14 @@ def test_gpu_shaders_and_materials_match_oracle(gpu, oracle, kind, world):
         bvh = oracle.Bvh(w, states) if world == "bvh" else None
         ref, states = oracle.render_ex(w, bvh, shader, ocam, nx, ny, spp, states, max_depth=depth)
         after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
-        for variant in ((0, 5, 6) if world == "bvh" and shader == api.SHADER_SHADE and depth == 8 else (0,)):
+        # shade: the walk's forced general modes and the skip links; LambertShade with materials: the tiled kernels (0; list world also
+        # with tiny capacities = shared tiles and the pool fallback, 3, and with a full binning log, 8) and the generic kernel (1)
+        variants = (0,)
+        if world == "bvh" and shader == api.SHADER_SHADE and depth == 8:
+            variants = (0, 5, 6, 9)
+        elif shader == api.SHADER_LAMBERT:
+            variants = (0, 1, 3, 8) if world == "list" else (0, 1)
+        for variant in variants:
             st = api.SetCurandState(nx, ny, 0)
             if world == "bvh":
                 api.create_BVHfromList(scene, st)      # the reference's order: SetCurandState, build, render
@@ -153,9 +160,10 @@ def test_gpu_shaders_and_materials_match_oracle(gpu, oracle, kind, world):
 
 @pytest.mark.gpu
 def test_gpu_lambert_entry_points_follow_the_material_table(gpu, oracle):
-    """crt_render_rows / crt_render_rows_bvh on a scene whose table is not one Lambertian run the
-    generic kernel (same pixels as the oracle's LambertShade with those materials); setting the
-    table back to one Lambertian restores the specialised kernels and their pixels."""
+    """crt_render_rows / crt_render_rows_bvh on a scene whose table is not one Lambertian shade every hit with its own
+    material (the tiled kernels' material mode, or the generic kernel where they are not eligible: same pixels as the
+    oracle's LambertShade with those materials); setting the table back to one Lambertian restores the specialised
+    kernels and their pixels."""
     sc, of = material_scene("spheres")
     nx, ny, spp = 64, 40, 2
     w, ocam = oracle_world(oracle, sc, of, nx, ny)
@@ -181,6 +189,43 @@ def test_gpu_lambert_entry_points_follow_the_material_table(gpu, oracle):
         api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, shader=api.SHADER_SHADE, max_depth=40)
     with pytest.raises(_lib.CrtError):
         scene.set_materials([(9, (0, 0, 0), 0.0)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", ["list", "bvh"])
+def test_gpu_lambert_materials_through_the_tiled_kernels_on_a_dense_pile(gpu, oracle, world):
+    """LambertShade with a Material* per triangle rides the tiled kernels (render_pixel<.., MAT>): what a hit draws depends
+    on the hit triangle's material class, so the shared tiles' master wave cannot run the hit branch's draws ahead.  A pile
+    of 2500 overlapping triangles puts hundreds of entries into every central tile (shared tiles, chunked staging in the BVH
+    world) with all four classes mixed: pixels and RNG states against the oracle, and against the generic kernel."""
+    rng = np.random.RandomState(77)
+    n = 2500
+    c = np.stack([rng.uniform(-0.6, 0.6, n), rng.uniform(-0.6, 0.6, n), rng.uniform(-9, -5, n)], axis=-1)
+    tri = c[:, None, :] + rng.uniform(-0.5, 0.5, (n, 3, 3))
+    sc = dict(points=tri.reshape(-1, 3).astype(np.float32), idx=np.arange(n * 3, dtype=np.float32).reshape(n, 3), normals=None, index_base=0,
+              camera=dict(lookfrom=(0.0, 0.0, 0.0), lookat=(0.0, 0.0, -1.0), vfov=60.0, aperture=0.0, focus=10.0))
+    of = rng.randint(0, len(MATS), n).astype(np.int32)
+    nx, ny, spp = 96, 64, 3
+    w, ocam = oracle_world(oracle, sc, of, nx, ny)
+    scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    cam = api.create_camera(nx, ny, (0.0, 0.0, 0.0), (0.0, 0.0, -1.0), 10.0, 0.0, 60.0)
+    states = oracle.fresh_states(nx, ny)
+    bvh = oracle.Bvh(w, states) if world == "bvh" else None
+    ref, states = oracle.render_ex(w, bvh, oracle.SHADER_LAMBERT, ocam, nx, ny, spp, states)
+    after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+    for variant in (0, 1):
+        st = api.SetCurandState(nx, ny, 0)
+        if world == "bvh":
+            api.create_BVHfromList(scene, st)
+        scene.set_materials(MATS, of)
+        if variant == 0:
+            api.tiled_stats(1)
+        got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH if world == "bvh" else api.WORLD_LIST, api.SHADER_LAMBERT, 8, variant)
+        if variant == 0:
+            stats = api.tiled_stats(0)
+            assert stats[4] > 0 and stats[6] > 64, stats[:8]          # the tiled kernels ran, and some tile holds more than one staging chunk
+        assert same(got, ref), (world, variant, int((bits(got) != bits(ref)).any(axis=2).sum()))
+        assert np.array_equal(st.export()[1:], after[1:]), (world, variant)
 
 
 @pytest.mark.gpu

@@ -3,6 +3,7 @@
     python3 tools/f_workload.py <which> [spp] [frames] [mesh]
 which:  shade        recursive `shade`, depth 8, 4 materials, BVH world     (render.h:48-67; spp default 4)
         lambert4     LambertShade with the same 4 materials, BVH world       (render.h:70-87; spp default 4)
+        lambert4_list  the same in the list world
         normal       shade_normal, BVH world                                 (render.h:90-103)
         bvh_walk     LambertShade, one Lambertian, BVH world, per-ray tree walk only (variant 1; spp default 4)
         bvh_tiled    LambertShade, one Lambertian, BVH world, tiled kernels  (the default path; spp default 64)
@@ -27,10 +28,10 @@ path, nx, ny, _ = scenes.baseline_obj(mesh, tempfile.mkdtemp())
 scene = api.Scene.from_obj(path, scale=1.0)
 cam = api.init_camera(nx, ny)
 st = api.SetCurandState(nx, ny, 0)
-if which != "list":
+if which not in ("list", "lambert4_list"):
     api.create_BVHfromList(scene, st)
 n = scene.n_triangles
-if which in ("shade", "lambert4", "normal"):
+if which in ("shade", "lambert4", "lambert4_list", "normal"):
     mats = [(api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0), (api.METAL, (0.8, 0.85, 0.88), 0.1), (api.DIELECTRIC, (1, 1, 1), 1.5),
             (api.DIFFUSE_LIGHT, (4.0, 4.0, 4.0), 0.0)]
     scene.set_materials(mats, (np.arange(n) // 2500 % 4).astype(np.int32))
@@ -43,6 +44,8 @@ def frame():
         api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=8, stream=s)
     elif which == "lambert4":
         api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_LAMBERT, max_depth=8, stream=s)
+    elif which == "lambert4_list":
+        api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_LIST, shader=api.SHADER_LAMBERT, max_depth=8, stream=s)
     elif which == "normal":
         api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_NORMAL, max_depth=8, stream=s)
     elif which == "bvh_walk":
