@@ -274,6 +274,35 @@ def main():
                    "tiles_with_geometry_frac": 1.0 - st_n[8] / max(st_n[4], 1),
                    "tile_survivors_sum": st_n[5], "tile_survivors_max": st_n[6]}
 
+    # SURVEY §8d's OTHER C3 mesh (small_bunny midpoint-subdivided twice on a ground grid, 100 000 triangles, no pole fan):
+    # the same configuration, the same camera, the same parity bar (tests/test_gpu_configs.py: C3B); reported beside
+    # the headline, never as it.
+    second = None
+    if rank == 0 and world == 1 and tiled and not args.no_extras:
+        from cudaraytracer_amd import scenes
+        path_b, nxb, nyb, _ = scenes.baseline_obj("C3B", tmpdir)
+        scene_b = api.Scene.from_obj(path_b, scale=1.0)
+        st_bb = api.SetCurandState(nxb, nyb, 0)
+        buf = torch.empty(nxb * nyb * 3, dtype=torch.float32, device="cuda")
+        api.tiled_stats(True)
+        api.render_rows(scene_b, camera, st_bb, nxb, nyb, args.spp, 0, nyb, buf, stream=stream)
+        torch.cuda.synchronize()
+        st_s = api.tiled_stats(False)
+        for _ in range(5):
+            api.render_rows(scene_b, camera, st_bb, nxb, nyb, args.spp, 0, nyb, buf, stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            api.render_rows(scene_b, camera, st_bb, nxb, nyb, args.spp, 0, nyb, buf, stream=stream)
+        torch.cuda.synchronize()
+        ms_2 = (time.perf_counter() - t1) / 20 * 1e3
+        second = {"workload": "BASELINE configs[2] on the other synthetic mesh SURVEY names: small_bunny.obj midpoint-subdivided twice (79 488 "
+                              "triangles) on a 641 x 16 ground grid (20 512) = %d triangles, no pole; triangle list, reference camera"
+                              % scene_b.n_triangles,
+                  "ms_per_frame": ms_2, "Mrays/s": nxb * nyb * args.spp / ms_2 / 1e3,
+                  "tiles_with_geometry_frac": 1.0 - st_s[8] / max(st_s[4], 1), "tile_survivors_sum": st_s[5], "tile_survivors_max": st_s[6]}
+        scene_b.close()
+
     # The same frame through the BVH world (the reference's shipped configuration, kernel.cu:97): not the
     # headline metric (north_star names the list path), reported beside it.
     bvh_world = None
@@ -391,6 +420,7 @@ def main():
             "kernels": kernels,
             "survivors": survivors,
             "screen_filling_variant": filling,
+            "second_workload": second,
             "bvh_world": bvh_world,
             "pcie_inclusive_one_call": pcie,
         }

@@ -1803,7 +1803,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     // queue follows the tile index, so a group is mostly a run of horizontally adjacent tiles, and the wave that
     // takes them one after the other writes their framebuffer rows back to back — 4 x 96 B of a row are three
     // full 128-B lines in the same L2 instead of four separately evicted partial ones.
-    constexpr unsigned kLightGroup = 4;
+    // (a launch with few tiles per CU — one rank's strips of a multi-GPU split — deals them ONE at a time, bits 27..29 of
+    // split_packed: its waves far outnumber its tiles with geometry, and a wave that takes four neighbours with geometry
+    // one after the other was the last to end, 250 us after waves that found only sky had gone: profiles/r3_tiled)
+    const unsigned kLightGroup = max(1u, (split_packed >> 27) & 7u);
     const unsigned n_groups = (n_light + kLightGroup - 1) / kLightGroup;
     int chunk = (int)((blockIdx.x * WAVES + wave) % kLightChunks);
     while (true) {
@@ -1857,155 +1860,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool store = x < p.nx && ly < p.row_count;
             const int px = min(x, p.nx - 1), ply = min(ly, p.row_count - 1);   // lanes off the image replay a valid pixel, unstored
             const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-            if (VREC && desc.y != kNoList && cnt > 4 * 64) {
-                // Very long lists (the poles of a lat-long mesh at 4K: up to ~2000 entries): every sample passes ALL chunks
-                // through the staging area, candidate masks included (no room to keep them); a lane off the hot chain or
-                // with an unreachable winner walks the tree for that sample.
-                const int n_chunks = (cnt + 63) / 64;
-                const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ply);
-                const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
-                const int first_level = __builtin_amdgcn_readfirstlane(
-                    tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[wave], lane));
-                render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
-                    const V3 c1 = rot0_exact(view.rot, d1);
-                    const V3 c2 = chain_next<true>(view.rot, c1);
-                    const V3 c3 = chain_next<true>(view.rot, c2);
-                    const V3 c4 = chain_next<true>(view.rot, c3);
-                    const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
-                                           fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
-                    const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f && dbg_repeat_in != -77;
-                    float tb = FLT_MAX;
-                    int q = -1;
-                    for (int c = 0; c < n_chunks; ++c) {
-                        const int n = min(64, cnt - 64 * c);
-                        const int e = (lane < n) ? (int)lst[64 * c + lane] : 0;
-                        Cand cd;
-                        stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, e, n, lane, px, gy, cd);
-                        if (lane < n) lent[wave][lane] = (int)(((unsigned)e & kCullSureBit) | (unsigned)(0x7fffffff - bt.partner[e & 0x7fffffff]));
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        if (!store) cd.lo = cd.hi = 0u;
-                        trace_candidates(lrec[wave], lent[wave], cd, c3, tb, q);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    int slot = -1;
-                    bool walk_it = !hot;
-                    if (hot && q >= 0) {
-                        slot = bt.partner[0x7fffffff - q];
-                        walk_it = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
-                    }
-                    hit_idx = slot;
-                    if (walk_it) {   // per lane (the walk's votes are taken among the lanes that are here)
-                        V3 used;
-                        bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
-                    }
-                    closest = 0.0f;
-                }, mv);
-                continue;
-            }
+            // (a light tile never holds more than the heavy threshold, at most 64 entries — bin_alloc_kernel queues anything longer
+            // as a shared tile — so one staging chunk serves it; rounds 1-2 carried two more paths here, for 65..256 and longer
+            // lists, that no launch could reach and that cost the kernel registers)
             if (!VREC || desc.y == kNoList) {   // no list (pool overflow): every sample walks the tree
                 render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     V3 used;
                     bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
-                }, mv);
-                continue;
-            }
-            if (cnt > 64) {
-                // 65..256 entries (the heavy tiles of the list world): chunks of 64.  The candidate masks of every
-                // chunk are found once per tile; per sample each chunk's exact records pass through the staging
-                // area again (one 64-B load per lane) and the winner is carried from chunk to chunk.
-                const int n_chunks = (cnt + 63) / 64;
-                const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ply);
-                Cand cc[4];
-                int ent_c[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    cc[c] = Cand{0u, 0u, 0u, 0u};
-                    ent_c[c] = 0;
-                    if (c < n_chunks) {
-                        const int n = min(64, cnt - 64 * c);
-                        ent_c[c] = (lane < n) ? (int)lst[64 * c + lane] : 0;
-                        stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, ent_c[c], n, lane, px, gy, cc[c]);
-                        if (!store) cc[c].lo = cc[c].hi = 0u;
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                }
-                const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
-                const int first_level = __builtin_amdgcn_readfirstlane(
-                    tile_reference_path(bt, __builtin_amdgcn_readfirstlane(ent_c[0] & 0x7fffffff), o, cone, lpath[wave], lane));
-                int q_c[4];   // tie order of this lane's entry in every chunk
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    q_c[c] = (c < n_chunks && lane < min(64, cnt - 64 * c))
-                                 ? (int)(((unsigned)ent_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bt.partner[ent_c[c] & 0x7fffffff])) : 0;
-                render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
-                    const V3 c1 = rot0_exact(view.rot, d1);
-                    const V3 c2 = chain_next<true>(view.rot, c1);
-                    const V3 c3 = chain_next<true>(view.rot, c2);
-                    const V3 c4 = chain_next<true>(view.rot, c3);
-                    const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
-                                           fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
-                    const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f && dbg_repeat_in != -77;   // -77: test hook, every lane takes the general path
-                    if (!hot) {   // off the hot chain (0.01 % of rays): this lane alone, with the chain element of every depth
-                        const V3 c5 = rot0(view.rot, unit_vector(c4));
-                        const int mode = same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2);
-                        const unsigned masks[8] = {cc[0].lo, cc[0].hi, cc[1].lo, cc[1].hi, cc[2].lo, cc[2].hi, cc[3].lo, cc[3].hi};
-                        unsigned gex[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-                        for (;;) {
-                            int slot = -1;
-                            const int q = general_winner(bt, rec, lst, cnt, masks, gex, 8, o, c1, c2, c3, c4, mode, slot);
-                            if (q < 0 || chain_ok_general(bt, slot, o, c1, c2, c3, c4, mode)) { hit_idx = slot; break; }
-                            for (int k = 0; k < cnt; ++k)
-                                if ((int)(lst[k] & 0x7fffffffu) == slot) {
-#pragma unroll
-                                    for (int j = 0; j < 8; ++j)
-                                        if ((k >> 5) == j) gex[j] |= 1u << (k & 31);
-                                }
-                        }
-                    }
-                    unsigned ex[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
-                    for (;;) {
-                        float tb = FLT_MAX;
-                        int q = -1;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (c >= n_chunks) continue;
-                            __builtin_amdgcn_wave_barrier();   // the previous chunk's reads are done
-                            if (lane < min(64, cnt - 64 * c)) {
-                                const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(ent_c[c] & 0x7fffffff) * kRecFloats);
-                                lrec[wave][0][lane] = r[0]; lrec[wave][1][lane] = r[1]; lrec[wave][2][lane] = r[2]; lrec[wave][3][lane] = r[3];
-                                lent[wave][lane] = q_c[c];
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            Cand rest = cc[c];
-                            rest.lo &= ~ex[c][0];
-                            rest.hi &= ~ex[c][1];
-                            trace_candidates(lrec[wave], lent[wave], rest, c3, tb, q);
-                        }
-                        int slot = -1;
-                        bool bad = false;
-                        if (q >= 0 && hot) {
-                            slot = bt.partner[0x7fffffff - q];
-                            bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
-                        }
-                        if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
-                            if (hot) hit_idx = slot;
-                            closest = 0.0f;
-                            break;
-                        }
-                        if (bad)   // exclude the unreachable winner for this pixel: find its position in the tile's list
-                            for (int k = 0; k < cnt; ++k)
-                                if ((int)(lst[k] & 0x7fffffffu) == slot) {
-#pragma unroll
-                                    for (int c = 0; c < 4; ++c)   // constant indices: the masks stay in registers
-#pragma unroll
-                                        for (int h = 0; h < 2; ++h)
-                                            if ((k >> 6) == c && ((k >> 5) & 1) == h) ex[c][h] |= 1u << (k & 31);
-                                }
-                    }
                 }, mv);
                 continue;
             }
@@ -2455,6 +2316,13 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
 #endif
     unsigned split_packed = 0;
     for (int c = 0; c < kHeavyClasses; ++c) split_packed |= (unsigned)split[c] << (3 * c);
+    // light tiles are dealt to the waves in groups of adjacent tiles (framebuffer rows written back to back: +3 % on a
+    // full frame) — but one at a time when the launch is small (see shade_tiles_kernel)
+    unsigned light_group = tiles_per_cu >= 96 ? 4u : 1u;
+#ifdef CRT_TUNING
+    if (const char* e = getenv("CRT_LIGHT_GROUP")) light_group = (unsigned)std::max(1, std::min(atoi(e), 7));
+#endif
+    split_packed |= light_group << 27;
     ShadeFn fn;
     if (group == 4) {   // experiment (CRT_SHADE_GROUP=4): half as many waves parked per shared tile, more blocks free for light tiles at once
         occ = 6;
