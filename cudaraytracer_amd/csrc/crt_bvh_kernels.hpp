@@ -73,6 +73,12 @@ __device__ __forceinline__ bool same_bits(V3 a, V3 b) {
            __float_as_uint(a.z) == __float_as_uint(b.z);
 }
 
+// component-wise select of VALUES (a conditional expression on two struct lvalues selects their ADDRESSES and loads: the
+// struct then has to live in scratch memory — 80 B per lane and 400 MB of write traffic per frame, measured)
+__device__ __forceinline__ V3 sel3(bool c, V3 a, V3 b) {
+    return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z};
+}
+
 // AABB::hit (core/aabb.h:30-43), literal: IEEE divisions, ffmin/ffmax as `a < b ? a : b`.
 __device__ __forceinline__ bool box_hit_ieee(float4 n0, float4 n1, V3 o, V3 d) {
     const float mn[3] = {n0.x, n0.y, n0.z}, mx[3] = {n0.w, n1.x, n1.y};
@@ -190,7 +196,7 @@ __device__ __forceinline__ void bvh_walk_fast(const BvhView& b, const float* __r
         const int depth = (info >> 26) & 31, count = (info >> 24) & 3, first = info & 0xffffff;
         V3 d = c3, y = y3;
         if (depth < 2) {   // the root sees F(d0), its children F^2(d0): three nodes of the whole tree
-            d = depth == 0 ? c1 : c2;
+            d = sel3(depth == 0, c1, c2);
             y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
         }
         const bool hit = box_hit_fast(n0, n1, o, d, y);
@@ -273,8 +279,8 @@ __device__ __forceinline__ bool bvh_walk_pairs(const BvhView& b, const float* __
             const float4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
             const int k = depth + 2;
             const bool box3 = pair_uses_c3(pd, k), tri3 = pd.cyc && (k & 1);   // k + 2 >= 4 has k's parity
-            const V3 d = (k == 2) ? pd.c2 : (box3 ? pd.c3 : pd.c4), y = (k == 2) ? pd.y2 : (box3 ? pd.y3 : pd.y4);
-            const V3 dt = tri3 ? pd.c3 : pd.c4;
+            const V3 d = sel3(k == 2, pd.c2, sel3(box3, pd.c3, pd.c4)), y = sel3(k == 2, pd.y2, sel3(box3, pd.y3, pd.y4));
+            const V3 dt = sel3(tri3, pd.c3, pd.c4);
             const bool hit_l = box_hit_fast(p0, make_float4(p1.x, p1.y, 0.0f, 0.0f), o, d, y);
             const bool hit_r = box_hit_fast(make_float4(p1.z, p1.w, p2.x, p2.y), make_float4(p2.z, p2.w, 0.0f, 0.0f), o, d, y);
             const int ref_l = __float_as_int(p3.x), ref_r = __float_as_int(p3.y);
@@ -310,7 +316,7 @@ __device__ __forceinline__ V3 chain_at(const float* m, int k, V3 c1, V3 c2, V3 c
     if (k == 2) return c2;
     if (k == 3) return c3;
     if (k == 4 || mode == 0) return c4;
-    if (mode == 1) return (k & 1) ? c3 : c4;
+    if (mode == 1) return sel3((k & 1) != 0, c3, c4);
     V3 c = c4;
     for (int j = 4; j < k; ++j) c = rot0(m, unit_vector(c));   // per lane: no wave votes in here
     return c;
@@ -543,7 +549,7 @@ __device__ __forceinline__ bool chain_ok(const BvhTiles& bt, int slot, int tile_
             const int k = min(k0 + j, depth);
             V3 d = c3, y = y3;
             if (k < 2) {
-                d = k == 0 ? c1 : c2;
+                d = sel3(k == 0, c1, c2);
                 y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
             }
             ok = ok && box_hit_fast(a[j], b[j], o, d, y);

@@ -1987,7 +1987,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                                 const int lv = min(first_k + j, depth);
                                 V3 d = c3, y = y3;
                                 if (lv < 2) {
-                                    d = lv == 0 ? c1 : c2;
+                                    d = sel3(lv == 0, c1, c2);
                                     y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
                                 }
                                 ok = ok && box_hit_fast(na[j], nb[j], o, d, y);

@@ -163,7 +163,7 @@ __device__ __forceinline__ V3 sky_of(V3 d) {   // backgroundSky(d), render.h:41-
 // shader: 0 LambertShade, 1 shade, 2 shade_normal.  256 threads = four 8x8 pixel tiles.
 template <bool FAST, bool BVH>
 #ifndef CRT_GENERIC_OCC
-#define CRT_GENERIC_OCC 0   // 0: no occupancy target beyond the block size
+#define CRT_GENERIC_OCC 4   // waves per SIMD the register allocation aims at (the pair walk sits at 129 VGPRs without a target: 3 waves)
 #endif
 #if CRT_GENERIC_OCC
 __global__ void __launch_bounds__(256, CRT_GENERIC_OCC)
