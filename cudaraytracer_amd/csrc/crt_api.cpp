@@ -839,7 +839,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     if (!scene || !camera || !rng || !d_rgb) return fail(CRT_ERR_INVALID, "crt_render_rows: null argument");
     // LambertShade with a material per triangle rides the tiled kernels too (the material only changes what a hit draws
     // and returns, crt_kernels.hip: render_pixel<.., MAT>) when they are eligible; variant 1 keeps the generic kernel (A/B)
-    const bool lambert_materials = shader == CRT_SHADER_LAMBERT && !scene->single_lambertian;
+    const bool lambert_materials = (shader == CRT_SHADER_LAMBERT && !scene->single_lambertian) || shader == CRT_SHADER_NORMAL;
     bool generic = shader != CRT_SHADER_LAMBERT || !scene->single_lambertian;
     if (world == 1 && !scene->bvh) return fail(CRT_ERR_INVALID, "crt_render_rows_bvh: the scene has no BVH (crt_scene_build_bvh)");
     if ((long long)nx * ny > 0x7fffffffLL)
@@ -904,6 +904,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         if (ok) {
             mat_view.material_of = world == 1 ? scene->bvh->d_material_slots : scene->d_material_of;
             mat_view.materials = static_cast<const crt::MaterialPOD*>(scene->d_materials);
+            mat_view.normal_shader = shader == CRT_SHADER_NORMAL ? 1 : 0;
             materials = &mat_view;
             generic = false;
         }

@@ -134,6 +134,7 @@ struct MaterialPOD {
 struct MatView {
     const int* material_of = nullptr;        // per triangle (list order) or per slot (BVH world); null = all 0
     const MaterialPOD* materials = nullptr;  // null: the scene's single Lambertian (RenderParams::albedo)
+    int normal_shader = 0;                   // != 0: shade_normal (render.h:90-103): a hit returns rec.normal, nothing is drawn
 };
 struct BvhTiles;
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,

@@ -627,6 +627,12 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
             const float snx = sn[0], sny = sn[1], snz = sn[2];         // requested before the draws: the latency overlaps them
             float ax = p.albedo[0], ay = p.albedo[1], az = p.albedo[2], ex = 0.0f, ey = 0.0f, ez = 0.0f;
             if constexpr (MAT) {
+                if (mv.normal_shader != 0) {                           // shade_normal, render.h:98: return rec.normal
+                    colx += snx;
+                    coly += sny;
+                    colz += snz;
+                    continue;
+                }
                 // mat_ptr->scatter(...) for its draws and `attenuation`, mat_ptr->emitted (render.h:78-79):
                 //   Lambertian / Metal: random_in_unit_sphere (material.h:66,87), attenuation = albedo
                 //   Dielectric: ONE uniform (material.h:134), attenuation = (1, 1, 1)

@@ -147,7 +147,7 @@ def test_gpu_shaders_and_materials_match_oracle(gpu, oracle, kind, world):
         variants = (0,)
         if world == "bvh" and shader == api.SHADER_SHADE and depth == 8:
             variants = (0, 5, 6, 9)
-        elif shader == api.SHADER_LAMBERT:
+        elif shader in (api.SHADER_LAMBERT, api.SHADER_NORMAL):
             variants = (0, 1, 3, 8) if world == "list" else (0, 1)
         for variant in variants:
             st = api.SetCurandState(nx, ny, 0)

@@ -25,7 +25,7 @@ of = (np.arange(n) // 2500 % 4).astype(np.int32)          # bands of materials a
 scene.set_materials(mats, of)
 d = torch.zeros(ny * nx * 3, dtype=torch.float32, device="cuda")
 s = torch.cuda.current_stream()
-for shader, name in ((api.SHADER_SHADE, "shade depth %d" % depth), (api.SHADER_LAMBERT, "LambertShade (generic kernel)"), (api.SHADER_NORMAL, "shade_normal")):
+for shader, name in ((api.SHADER_SHADE, "shade depth %d" % depth), (api.SHADER_LAMBERT, "LambertShade (4 materials: tiled kernels, material mode)"), (api.SHADER_NORMAL, "shade_normal (tiled kernels)")):
     api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=shader, max_depth=depth, stream=s)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
