@@ -893,7 +893,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     if (lambert_materials && tiled_ok) {
         // list world: any tiled variant with staged records; BVH world: only where the tiled mode below is taken (its
         // conditions, restated: fast arithmetic of the traversal, variant 0 or 2)
-        bool ok = world == 0 ? (g_variant == 0 || g_variant == 2 || g_variant == 3 || g_variant == 8) : (g_variant == 0 || g_variant == 2);
+        bool ok = world == 0 ? (g_variant == 0 || g_variant == 2 || g_variant == 3 || g_variant == 8 || g_variant == 10) : (g_variant == 0 || g_variant == 2);
         if (world == 1) {
             ok = ok && scene->bvh->coords_not_tiny;
             for (int k = 0; k < 3; ++k) {
@@ -914,6 +914,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     else if (g_variant == 3) kernel_variant = tiled_ok ? 2 : 0;
     else if (g_variant == 4) kernel_variant = tiled_ok ? 3 : 0;   // tiled, scalar-operand walk for light tiles too (A/B)
     else if (g_variant == 8) kernel_variant = tiled_ok ? 4 : 0;   // tiled with a 16-record binning log (overflow fallback)
+    else if (g_variant == 10) kernel_variant = tiled_ok ? 5 : 0;  // tiled, shared tiles from 4 entries on, dealt out as row slabs (sub-items)
 
     crt::RenderParams p;
     memcpy(p.cam.llc, camera->lower_left_corner, 12);

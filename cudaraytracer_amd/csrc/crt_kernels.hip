@@ -2300,7 +2300,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
 #endif
     // tiles with more survivors than this are shared by all waves of a block (measured: a full frame, and one
     // rank's strips of a 2-, 4-, 8-way split on the bench scene)
-    int heavy = (variant == 2) ? 3 : (tiles_per_cu >= 96 ? kHeavyMin : (tiles_per_cu >= 24 ? kHeavyMinMedium : kHeavyMinSmall));
+    int heavy = (variant == 2 || variant == 5) ? 3 : (tiles_per_cu >= 96 ? kHeavyMin : (tiles_per_cu >= 24 ? kHeavyMinMedium : kHeavyMinSmall));
     bool vrec = variant != 3;   // light tiles: records staged in LDS (VGPR operands); variant 3 keeps the scalar-operand walk (A/B)
 #ifdef CRT_TUNING
     if (const char* e = getenv("CRT_HEAVY_MIN")) heavy = std::max(1, std::min(atoi(e), 64));
@@ -2315,6 +2315,8 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     // length), not the longest list; splitting the common classes only replicates the master wave's work (+20 .. +90 %).
     // So the default is no split; the mechanism stays for the tuning build (CRT_SPLIT) and for frames with far longer lists.
     int split[kHeavyClasses] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (variant == 5)   // test hook (crt_set_kernel_variant(10)): shared tiles from 4 entries on, dealt out as 2, 4 or 8 row slabs by class
+        for (int c = 0; c < kHeavyClasses; ++c) split[c] = 1 + c % 3;
 #ifdef CRT_TUNING
     if (const char* e = getenv("CRT_SPLIT")) {   // nine digits, e.g. CRT_SPLIT=222222100
         for (int c = 0; c < kHeavyClasses && e[c] >= '0' && e[c] <= '3'; ++c) split[c] = e[c] - '0';
@@ -2324,7 +2326,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     for (int c = 0; c < kHeavyClasses; ++c) split_packed |= (unsigned)split[c] << (3 * c);
     // light tiles are dealt to the waves in groups of adjacent tiles (framebuffer rows written back to back: +3 % on a
     // full frame) — but one at a time when the launch is small (see shade_tiles_kernel)
-    unsigned light_group = tiles_per_cu >= 96 ? 4u : 1u;
+    unsigned light_group = (tiles_per_cu >= 96 && variant != 5) ? 4u : 1u;
 #ifdef CRT_TUNING
     if (const char* e = getenv("CRT_LIGHT_GROUP")) light_group = (unsigned)std::max(1, std::min(atoi(e), 7));
 #endif

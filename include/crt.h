@@ -273,7 +273,8 @@ int crt_render_rows_ex(const crt_scene *scene, const crt_camera *camera, crt_rng
  * 1 = brute-force list walk, 2 = tiled, 3 = tiled with a tiny survivor pool and heavy-tile
  * threshold (test hook for the overflow fallback and the shared-tile path), 4 = tiled with
  * scalar-operand (SGPR) list walks instead of the LDS-staged records and per-pixel candidate
- * masks (A/B), 8 = tiled with a 16-record binning log (test hook for its overflow fallback); BVH world only: 1 = the per-ray tree walk instead of the tiled kernels, 5 = the walk's
+ * masks (A/B), 8 = tiled with a 16-record binning log (test hook for its overflow fallback), 10 = tiled with shared tiles from
+ * 4 entries on, each dealt out as 2, 4 or 8 row slabs to different blocks (test hook of the sub-item path); BVH world only: 1 = the per-ray tree walk instead of the tiled kernels, 5 = the walk's
  * general loop for every wavefront, 6 = the same with every direction chain iterated from its
  * fourth element, 7 = the tiled kernels with every lane on their general per-lane path (test hooks
  * for the rare paths), 9 = crt_render_rows_ex with the recursive shader walks the skip links of the flat node array instead of the

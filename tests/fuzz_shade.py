@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised soak of the generic kernel (recursive shade / LambertShade / shade_normal, the four material classes, both
+"""Randomised soak of crt_render_rows_ex (recursive shade over the pair records; LambertShade with materials and shade_normal
+through the tiled kernels' material mode; the four material classes, both
 worlds) against the CPU oracle — the loop of tests/test_shade.py::test_gpu_shade_random_soups_match_oracle on a time budget.
 Lives under tests/ because it uses the oracle.   usage: python tests/fuzz_shade.py [seconds] [first_seed]"""
 import os

@@ -12,7 +12,7 @@ from cudaraytracer_amd import _lib, api, scenes
 pytestmark = pytest.mark.gpu
 
 
-VARIANTS = {"brute": 1, "tiled": 2, "tiled_tinycaps": 3, "tiled_scalar_light": 4, "tiled_tinylog": 8}
+VARIANTS = {"brute": 1, "tiled": 2, "tiled_tinycaps": 3, "tiled_scalar_light": 4, "tiled_tinylog": 8, "tiled_row_slabs": 10}
 
 
 @pytest.fixture(params=sorted(VARIANTS))

@@ -37,7 +37,7 @@ while time.time() - t0 < budget:
     scene = api.Scene.from_mesh(pts, idx, normals, 0)
     cam = api.create_camera(nx, ny, tuple(lf), tuple(lf + w), focus, 0.0, vfov)
     outs = []
-    for v in (1, 2):
+    for v in (1, 2, 10):   # brute force, tiled, tiled with shared tiles from 4 entries on dealt out as row slabs
         prev = L.crt_set_kernel_variant(v)
         st = api.SetCurandState(nx, ny, seed)
         d = torch.zeros(nx * ny * 3, device="cuda")
@@ -45,7 +45,7 @@ while time.time() - t0 < budget:
         torch.cuda.synchronize()
         L.crt_set_kernel_variant(prev)
         outs.append((d.cpu().numpy().view(np.uint32), st.export()))
-    ok = np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ok = all(np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) for o in outs[1:])
     audit = None
     try:
         audit = api.audit_tiles(scene, cam, nx, ny, 2)
