@@ -175,6 +175,7 @@ struct Builder {
 crt_bvh::~crt_bvh() {
     if (d_nodes) (void)hipFree(d_nodes);
     if (d_pairs) (void)hipFree(d_pairs);
+    if (d_pair_flat) (void)hipFree(d_pair_flat);
     if (d_base_slots) (void)hipFree(d_base_slots);
     if (d_shade_n_slots) (void)hipFree(d_shade_n_slots);
     if (d_idx_slots) (void)hipFree(d_idx_slots);
@@ -276,15 +277,54 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
             ++ord;
         }
     }
-    // pair records (crt_bvh_kernels.hpp: bvh_walk_pairs): one per inner node, preorder over the inner nodes; the references are
-    // static, the boxes are copied from the flat nodes on the device (after this upload and after every refit)
+    // pair records (crt_bvh_kernels.hpp: bvh_walk_pairs): one per inner node, preorder over the inner nodes; the references and
+    // the normal cones are static, the boxes are copied from the flat nodes on the device (after this upload and after every refit)
     std::vector<float4> pairs;
+    std::vector<int> pair_flat;
     if (b.max_depth + 1 <= crt::kPairStackDepth) {   // one stack entry per level (bvh_walk_pairs)
-        std::vector<int> pair_of((size_t)t->n_nodes, -1);
+        std::vector<int> pair_of((size_t)t->n_nodes, -1), first_slot((size_t)t->n_nodes + 1, n);
         int n_inner = 0;
         for (int i = 0; i < t->n_nodes; ++i)
             if (b.nodes[i].count == 0) pair_of[i] = n_inner++;
+        for (int i = t->n_nodes - 1; i >= 0; --i) first_slot[i] = b.nodes[i].count ? b.nodes[i].first : first_slot[i + 1];
+        // unit stored normals in slot order (what Triangle::collision_detection's first test multiplies the direction with,
+        // triangle.h:61); non-finite or zero normals never satisfy `dot < 0` for sure: their subtrees get no cone
+        std::vector<double> un((size_t)n * 3);
+        std::vector<char> bad((size_t)n, 0);
+        for (int slot = 0; slot < n; ++slot) {
+            const float* nr = s->h_base.data() + (size_t)b.order[slot] * crt::kBaseFloats + 9;
+            const double len = std::sqrt((double)nr[0] * nr[0] + (double)nr[1] * nr[1] + (double)nr[2] * nr[2]);
+            if (!(len > 0.0) || !std::isfinite(len)) { bad[slot] = 1; continue; }
+            for (int k = 0; k < 3; ++k) un[(size_t)slot * 3 + k] = nr[k] / len;
+        }
+        // Normal cone of a subtree as one word: axis as three signed bytes / 127, threshold byte T = byte * kConeScale.  The walk
+        // skips the subtree when  d . (qx, qy, qz) < -T * 127:  every stored normal n_i then has d . n_i < -1e-3 |d| |n_i|,
+        // three orders of magnitude beyond the rounding of the reference's float dot product, so its first test rejects every
+        // triangle of the subtree (none of them could be the hit, and nothing else of a rejected triangle is observable).
+        auto cone_of = [&](int node) -> unsigned {
+            const int s0 = first_slot[node], s1 = (b.nodes[node].skip < t->n_nodes) ? first_slot[b.nodes[node].skip] : n;
+            double ax = 0.0, ay = 0.0, az = 0.0;
+            for (int k = s0; k < s1; ++k) {
+                if (bad[k]) return 0xffu;
+                ax += un[(size_t)k * 3]; ay += un[(size_t)k * 3 + 1]; az += un[(size_t)k * 3 + 2];
+            }
+            const double al = std::sqrt(ax * ax + ay * ay + az * az);
+            if (!(al > 1e-9 * (double)(s1 - s0))) return 0xffu;
+            const int qx = (int)std::lround(ax / al * 127.0), qy = (int)std::lround(ay / al * 127.0), qz = (int)std::lround(az / al * 127.0);
+            const double dx = qx / 127.0, dy = qy / 127.0, dz = qz / 127.0, dl = std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (!(dl > 0.5)) return 0xffu;
+            double min_cos = 1.0;
+            for (int k = s0; k < s1; ++k)
+                min_cos = std::min(min_cos, (un[(size_t)k * 3] * dx + un[(size_t)k * 3 + 1] * dy + un[(size_t)k * 3 + 2] * dz) / dl);
+            if (!(min_cos > 0.05)) return 0xffu;                                    // half angle towards 90 degrees: nothing to gain
+            const double sin_t = std::sqrt(std::max(0.0, 1.0 - min_cos * min_cos));
+            const double T = (sin_t + 1.0e-3) * 1.0001 * dl + 2.0e-5;               // |d| <= 1 + 1e-5; float evaluation of the dot product
+            const int byte = (int)std::ceil(T / crt::kConeScale);
+            if (byte > 254) return 0xffu;
+            return (unsigned)byte | ((unsigned)(qx & 0xff) << 8) | ((unsigned)(qy & 0xff) << 16) | ((unsigned)(qz & 0xff) << 24);
+        };
         pairs.assign((size_t)4 * n_inner, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        pair_flat.assign((size_t)2 * n_inner, 0);
         auto ref_of = [&](int node) {
             const HostNode& nd = b.nodes[node];
             return nd.count ? (int)(0x80000000u | ((unsigned)nd.count << 24) | (unsigned)nd.first) : pair_of[node];
@@ -292,10 +332,12 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
         for (int i = 0; i < t->n_nodes; ++i) {
             if (b.nodes[i].count != 0) continue;
             const int l = i + 1, r = b.nodes[l].skip;   // the left child follows its parent; its skip link is the right child
-            const int refs[4] = {ref_of(l), ref_of(r), l, r};
+            const int refs[4] = {ref_of(l), ref_of(r), (int)cone_of(l), (int)cone_of(r)};
             float4 p3;
             memcpy(&p3, refs, sizeof p3);
             pairs[(size_t)4 * pair_of[i] + 3] = p3;
+            pair_flat[(size_t)2 * pair_of[i]] = l;
+            pair_flat[(size_t)2 * pair_of[i] + 1] = r;
         }
         t->n_pairs = n_inner;
     }
@@ -333,8 +375,10 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
     if (e == hipSuccess) e = hipMemcpy(t->d_level_nodes, level_nodes.data(), level_nodes.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess && t->n_pairs > 0) {
         e = hipMalloc(&t->d_pairs, pairs.size() * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc(&t->d_pair_flat, pair_flat.size() * sizeof(int));
         if (e == hipSuccess) e = hipMemcpy(t->d_pairs, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = crt::launch_bvh_pairs(t->d_nodes, t->d_pairs, t->n_pairs, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(t->d_pair_flat, pair_flat.data(), pair_flat.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = crt::launch_bvh_pairs(t->d_nodes, t->d_pairs, t->d_pair_flat, t->n_pairs, nullptr);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     }
     if (e == hipSuccess) e = hipMalloc(&t->d_partner, partner.size() * sizeof(int));
@@ -376,7 +420,7 @@ int crt_scene_refit_bvh(crt_scene* s, void* stream_) {
         const int at = t->level_offset[level], cnt = t->level_offset[level + 1] - at;
         HIP_TRY(crt::launch_bvh_refit_level(t->d_nodes, t->d_level_nodes + at, cnt, t->d_base_slots, t->rot, (hipStream_t)stream_));
     }
-    HIP_TRY(crt::launch_bvh_pairs(t->d_nodes, t->d_pairs, t->n_pairs, (hipStream_t)stream_));   // the pair records carry copies of the boxes
+    HIP_TRY(crt::launch_bvh_pairs(t->d_nodes, t->d_pairs, t->d_pair_flat, t->n_pairs, (hipStream_t)stream_));   // the pair records carry copies of the boxes
     return CRT_OK;
 }
 

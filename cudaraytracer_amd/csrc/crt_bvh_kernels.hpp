@@ -38,8 +38,9 @@ struct BvhView {
     int n_nodes;
     float rot[9];   // rows of rotate(., vec3(0)) as the reference computes them (host, crt_bvh.cpp)
     // pair records (bvh_walk_pairs): one per INNER node, preorder over the inner nodes, 4 float4 = 64 B:
-    //   p0 = (L.min.xyz, L.max.x)  p1 = (L.max.yz, R.min.xy)  p2 = (R.min.z, R.max.xyz)  p3 = (refL, refR, flatL, flatR) as int bits
-    //   ref: child is a leaf ? 0x80000000 | count << 24 | first slot : the child's pair index;  flat: the child's node index
+    //   p0 = (L.min.xyz, L.max.x)  p1 = (L.max.yz, R.min.xy)  p2 = (R.min.z, R.max.xyz)  p3 = (refL, refR, coneL, coneR) as int bits
+    //   ref: child is a leaf ? 0x80000000 | count << 24 | first slot : the child's pair index
+    //   cone: the normal cone of the child's subtree (threshold byte | axis x, y, z as signed bytes; 0xff in the low byte: none)
     // null: the walks below use `nodes` only.
     const float4* pairs = nullptr;
     const int* partner = nullptr;   // BvhTiles::partner: the tie order as one key (larger wins among equal t)
@@ -229,6 +230,14 @@ __device__ __forceinline__ bool pair_uses_c3(const PairDirs& pd, int k) {   // k
     return k == 3 || (pd.cyc && (k & 1));
 }
 
+// The normal cone of a subtree (host: crt_bvh.cpp, cone_of): true when every stored normal n_i of the subtree has
+// d . n_i < 0 with a margin of 1e-3 |d| |n_i| — whichever chain element (c3 or c4, a few ulp apart) its triangles see.
+__device__ __forceinline__ bool cone_rejects(unsigned cone, V3 d) {
+    const float qx = (float)((int)(cone << 16) >> 24), qy = (float)((int)(cone << 8) >> 24), qz = (float)((int)cone >> 24);
+    const float t127 = (float)(cone & 0xffu) * (kConeScale * 127.0f);
+    return (cone & 0xffu) != 0xffu && d.x * qx + d.y * qy + d.z * qz < -t127;
+}
+
 template <bool PRIMARY>
 __device__ __forceinline__ void pair_tri(const BvhView& b, const float* __restrict__ rec, int slot, V3 o, V3 dt, float& best_t, int& best_slot,
                                          V3& dir_used) {
@@ -284,9 +293,12 @@ __device__ __forceinline__ bool bvh_walk_pairs(const BvhView& b, const float* __
             const bool hit_l = box_hit_fast(p0, make_float4(p1.x, p1.y, 0.0f, 0.0f), o, d, y);
             const bool hit_r = box_hit_fast(make_float4(p1.z, p1.w, p2.x, p2.y), make_float4(p2.z, p2.w, 0.0f, 0.0f), o, d, y);
             const int ref_l = __float_as_int(p3.x), ref_r = __float_as_int(p3.y);
-            if (hit_l && ref_l < 0) pair_leaf<PRIMARY>(b, rec, ref_l, o, dt, best_t, best_slot, dir_used);
-            if (hit_r && ref_r < 0) pair_leaf<PRIMARY>(b, rec, ref_r, o, dt, best_t, best_slot, dir_used);
-            const bool go_l = hit_l && ref_l >= 0, go_r = hit_r && ref_r >= 0;
+            // a child whose subtree's stored normals ALL have d . n < 0 beyond rounding holds no triangle that passes the
+            // first test of Triangle::collision_detection (triangle.h:61): it is skipped like a missed box
+            const bool try_l = hit_l && !cone_rejects(__float_as_uint(p3.z), dt), try_r = hit_r && !cone_rejects(__float_as_uint(p3.w), dt);
+            if (try_l && ref_l < 0) pair_leaf<PRIMARY>(b, rec, ref_l, o, dt, best_t, best_slot, dir_used);
+            if (try_r && ref_r < 0) pair_leaf<PRIMARY>(b, rec, ref_r, o, dt, best_t, best_slot, dir_used);
+            const bool go_l = try_l && ref_l >= 0, go_r = try_r && ref_r >= 0;
             ++depth;
             if (go_l && go_r) {
                 overflow = sp >= kPairStackDepth;
@@ -746,20 +758,19 @@ bvh_refit_level_kernel(float4* __restrict__ nodes, const int* __restrict__ level
 // Pair records from the flat nodes (after the build's upload and after every refit): lane = inner node; the boxes of its two
 // children are copied next to each other (bvh_walk_pairs); the references p3 are static (host, crt_bvh.cpp).
 __global__ void __launch_bounds__(256)
-bvh_pairs_kernel(const float4* __restrict__ nodes, float4* __restrict__ pairs, int n_pairs) {
+bvh_pairs_kernel(const float4* __restrict__ nodes, float4* __restrict__ pairs, const int* __restrict__ pair_flat, int n_pairs) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_pairs) return;
-    const float4 p3 = pairs[4 * (size_t)j + 3];
-    const int l = __float_as_int(p3.z), r = __float_as_int(p3.w);
+    const int l = pair_flat[2 * (size_t)j], r = pair_flat[2 * (size_t)j + 1];
     const float4 l0 = nodes[2 * (size_t)l], l1 = nodes[2 * (size_t)l + 1], r0 = nodes[2 * (size_t)r], r1 = nodes[2 * (size_t)r + 1];
     pairs[4 * (size_t)j + 0] = l0;                                          // L.min.xyz, L.max.x
     pairs[4 * (size_t)j + 1] = make_float4(l1.x, l1.y, r0.x, r0.y);         // L.max.yz, R.min.xy
     pairs[4 * (size_t)j + 2] = make_float4(r0.z, r0.w, r1.x, r1.y);         // R.min.z, R.max.xyz
 }
 
-hipError_t launch_bvh_pairs(const float4* d_nodes, float4* d_pairs, int n_pairs, hipStream_t stream) {
+hipError_t launch_bvh_pairs(const float4* d_nodes, float4* d_pairs, const int* d_pair_flat, int n_pairs, hipStream_t stream) {
     if (n_pairs <= 0 || d_pairs == nullptr) return hipSuccess;
-    hipLaunchKernelGGL(bvh_pairs_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, d_nodes, d_pairs, n_pairs);
+    hipLaunchKernelGGL(bvh_pairs_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, d_nodes, d_pairs, d_pair_flat, n_pairs);
     return hipGetLastError();
 }
 

@@ -174,7 +174,8 @@ hipError_t launch_render_bvh(const RenderParams& p, const float4* d_nodes, int n
                              const float* d_shade_n, uint32_t* d_state, float* d_rgb, bool fast, int force_mode,
                              hipStream_t stream);
 // pair records of the tree (crt_bvh_kernels.hpp: bvh_walk_pairs): boxes refreshed from the flat nodes
-hipError_t launch_bvh_pairs(const float4* d_nodes, float4* d_pairs, int n_pairs, hipStream_t stream);
+hipError_t launch_bvh_pairs(const float4* d_nodes, float4* d_pairs, const int* d_pair_flat, int n_pairs, hipStream_t stream);
+constexpr float kConeScale = 1.02f / 254.0f;   // threshold byte of a pair record's normal cone -> threshold (crt_bvh.cpp: cone_of)
 constexpr int kPairStackDepth = 24;   // entries of the per-lane stack of bvh_walk_pairs (one per tree level); deeper trees keep the skip-link walk
 // The generic render kernel (crt_shade_kernels.hpp): shader 0 LambertShade, 1 shade (recursive, depth
 // <= max_depth < kMaxShadeDepth), 2 shade_normal; world = list (d_nodes null) or BVH; per-triangle

@@ -101,6 +101,7 @@ struct crt_bvh {
     int n_nodes = 0, max_depth = 0;
     float4* d_nodes = nullptr;          // 2 float4 per node, preorder (crt_bvh_kernels.hpp)
     float4* d_pairs = nullptr;          // 4 float4 per INNER node: both children's boxes + references (bvh_walk_pairs); null for trees deeper than kPairStackDepth
+    int* d_pair_flat = nullptr;         // per pair: the flat node indices of its two children (bvh_pairs_kernel copies their boxes)
     int n_pairs = 0;
     float* d_base_slots = nullptr;      // n x 12 base records in slot order
     float* d_shade_n_slots = nullptr;   // n x 3 shading normals in slot order (rotate(., 0) applied depth + 3 times)
