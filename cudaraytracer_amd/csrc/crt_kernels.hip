@@ -2313,8 +2313,11 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     // x2 .. x8 changes neither the full frame nor the slowest rank of an 8-way split, on either C3 mesh — what bounds a
     // small launch is the 64-sample chain of EVERY tile that holds geometry (about 2 us per sample whatever the list's
     // length), not the longest list; splitting the common classes only replicates the master wave's work (+20 .. +90 %).
-    // So the default is no split; the mechanism stays for the tuning build (CRT_SPLIT) and for frames with far longer lists.
+    // So the default is no split — except for lists of more than 768 entries (the two ~1 980-entry pole tiles of the C5 frame end
+    // its launch alone: 4.83 -> 4.06 ms with four slabs each, profiles/r3_tiled/c5_split.txt); list world only (the BVH mode's
+    // shared tiles are tested without slabs).  The mechanism stays for the tuning build (CRT_SPLIT).
     int split[kHeavyClasses] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (d_bvh_tiles == nullptr) split[0] = 2;
     if (variant == 5)   // test hook (crt_set_kernel_variant(10)): shared tiles from 4 entries on, dealt out as 2, 4 or 8 row slabs by class
         for (int c = 0; c < kHeavyClasses; ++c) split[c] = 1 + c % 3;
 #ifdef CRT_TUNING
