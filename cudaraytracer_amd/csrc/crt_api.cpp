@@ -895,7 +895,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         // conditions, restated: fast arithmetic of the traversal, variant 0 or 2)
         bool ok = world == 0 ? (g_variant == 0 || g_variant == 2 || g_variant == 3 || g_variant == 8 || g_variant == 10) : (g_variant == 0 || g_variant == 2);
         if (world == 1) {
-            ok = ok && scene->bvh->coords_not_tiny;
+            ok = ok && scene->bvh->coords_not_tiny && scene->n_tris <= (1 << 22);
             for (int k = 0; k < 3; ++k) {
                 const float o = camera->origin[k];
                 ok = ok && std::isfinite(o) && fabsf(o) <= 274877906944.0f && (o == 0.0f || fabsf(o) >= 1.3877787807814457e-17f);
@@ -967,7 +967,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         // Primary rays ride the tiled kernels (binning over the slot-ordered triangles, the tree only for every
         // pixel's winner: shade_tiles_kernel<.., BVH>) whenever the list world's tiled variant is eligible and
         // the fast arithmetic holds; variant 1 (and the test hooks 5, 6) select the per-ray tree walk.
-        if (fast && tiled_ok && (g_variant == 0 || g_variant == 2 || g_variant == 7)) {
+        if (fast && tiled_ok && scene->n_tris <= (1 << 22) && (g_variant == 0 || g_variant == 2 || g_variant == 7)) {   // (22 bits of tie order in the keys)
             int rc = ensure_workspace(cx, nx, row_count, scene->n_tris);
             if (rc != CRT_OK) return rc;
             HIP_TRY(crt::launch_frame_prepass(scene->bvh->d_base_slots, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));

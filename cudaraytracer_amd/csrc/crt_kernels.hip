@@ -1392,6 +1392,28 @@ __device__ __forceinline__ unsigned long long hit_key(float t, int idx) {
     return ((unsigned long long)ordered << 32) | (unsigned long long)(unsigned)idx;
 }
 
+// The t of a key (inverse of hit_key's order-preserving map; -0 comes back as +0, which no comparison tells apart).
+__device__ __forceinline__ float key_t(unsigned long long key) {
+    const unsigned ordered = (unsigned)(key >> 32);
+    return __uint_as_float((ordered & 0x80000000u) ? (ordered & 0x7fffffffu) : ~ordered);
+}
+
+// BVH mode: is the chain of boxes of a winner passed for sure?  The boxes of a leaf's ancestors contain the leaf's box
+// (surrounding_box, aabb.h:58-66), so a ray that passes through a point STRICTLY inside the leaf's box — by a margin
+// that covers (i) the rounding of every quotient of AABB::hit (2^-22 relative to the slab distances), (ii) the few ulp
+// by which the directions of the levels (c1, c2, c3) differ, t * 2^-22 at the hit point, (iii) the rounding of the
+// point itself — has t_min < t < t_max on every axis of every one of those boxes, with t > 0.001: AABB::hit returns true
+// at every level.  The point is the hit point o + t * c3 of the triangle that won.  A flat box (a zero extent: never
+// hit, aabb.h:40) has no interior, a hit too close to a face or to the eye is not proven: those take the node loads.
+__device__ __forceinline__ bool hit_inside_leaf_box(float4 b0, float2 b1, V3 o, V3 c3, float t) {
+    const float px = o.x + t * c3.x, py = o.y + t * c3.y, pz = o.z + t * c3.z;
+    const float at = fabsf(t) * 1.0e-6f;
+    const float mx = 1.0e-4f * (b0.w - b0.x) + 2.0e-6f * (fabsf(o.x) + fabsf(px)) + at;
+    const float my = 1.0e-4f * (b1.x - b0.y) + 2.0e-6f * (fabsf(o.y) + fabsf(py)) + at;
+    const float mz = 1.0e-4f * (b1.y - b0.z) + 2.0e-6f * (fabsf(o.z) + fabsf(pz)) + at;
+    return t >= 0.01f && t <= 1.0e30f && px - b0.x > mx && b0.w - px > mx && py - b0.y > my && b1.x - py > my && pz - b0.z > mz && b1.y - pz > mz;
+}
+
 // ---- balanced candidate walk.  The step count of trace_candidates is the LONGEST per-pixel list
 // of the wavefront while the mean is much shorter.  When the (pixel, entry) pairs of the staged
 // entries fit the wave's pair buffer they are laid out once per tile, evenly over the lanes:
@@ -1498,6 +1520,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     __shared__ int lslot[BVH ? WAVES : 1][BVH ? 64 : 1];
     __shared__ int linfo[BVH ? WAVES : 1][BVH ? 64 : 1];
     __shared__ __attribute__((aligned(16))) int lnodes[BVH ? WAVES : 1][BVH ? 64 : 1][kChainBatch];
+    // ... and the box of its LEAF (min.xyz, max.x | max.yz): a ray whose hit point lies strictly inside it passes every box of the chain
+    // (hit_inside_leaf_box), so the common sample needs no node loads at all
+    __shared__ float4 lbox0[BVH ? WAVES : 1][BVH ? 64 : 1];
+    __shared__ float2 lbox1[BVH ? WAVES : 1][BVH ? 64 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1613,12 +1639,54 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         __builtin_amdgcn_wave_barrier();
                     }
             }
-            if (BVH && !tree_tile && n_lds > 0) {
-                if (lane < n_lds)   // the tree's tie order instead of the slot (see the light tiles)
-                    lent[wave][lane] = (int)(((unsigned)slice_mine & kCullSureBit) | (unsigned)(0x7fffffff - bvh->partner[slice_mine & 0x7fffffff]));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // BVH mode: the levels of the tree proven hit for every ray of the tile along its first entry's path (every wave
+            // works it out for itself, into its own lpath), and for a staged slice — like a light tile's list — per entry:
+            // the tree's tie order with the entry's place (wave, position) in the low bits of the key, its slot, where its
+            // path leaves the reference path, and the node indices of the levels from there on.  The master then finds the
+            // winner's staged data one LDS read away and needs ONE round of node loads for the chain test (rounds 1-2 went
+            // through slot_leaf, the ancestor table and the nodes: three dependent round trips per sample, 3.3 us of the
+            // 7.5 us a shared tile's sample took).
+            int first_level_h = 0;
+            if (BVH && !tree_tile && !skip_item) {
+                const BvhTiles& bt = *bvh;
+                const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
+                const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, tly0));
+                first_level_h = __builtin_amdgcn_readfirstlane(
+                    tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[wave], lane));
+                if (!multi && n_lds > 0) {
+                    if (lane < n_lds) {
+                        const int slot = slice_mine & 0x7fffffff;
+                        // key: (tie order, 22 bits: smaller wins = later leaf, first in its leaf) | wave | position (host: at most 2^22 triangles)
+                        lent[wave][lane] = (int)(((unsigned)slice_mine & kCullSureBit) | ((unsigned)(0x3fffff - bt.partner[slot]) << 9) |
+                                                 ((unsigned)wave << 6) | (unsigned)lane);
+                        const int info = bt.slot_leaf[slot];
+                        const int depth = (info >> 24) & 31;
+                        const int* __restrict__ path = bt.anc + (size_t)(info & 0xffffff) * bt.anc_stride;
+                        int first_k = first_level_h;   // where this entry's path leaves the reference path, if earlier
+                        for (int k = 0; k < first_level_h && k <= depth; k += 4) {
+                            const int4 ids = *reinterpret_cast<const int4*>(path + k);
+                            const int4 ref = *reinterpret_cast<const int4*>(&lpath[wave][k]);
+                            int d = 4;
+                            if (ids.w != ref.w) d = 3;
+                            if (ids.z != ref.z) d = 2;
+                            if (ids.y != ref.y) d = 1;
+                            if (ids.x != ref.x) d = 0;
+                            if (d < 4) { first_k = min(first_k, k + d); break; }
+                        }
+                        first_k = min(first_k, depth);   // the leaf's own box is always tested
+                        lslot[wave][lane] = slot;
+                        linfo[wave][lane] = depth | (first_k << 8) | ((depth - first_k + 1 > kChainBatch) ? (1 << 16) : 0);
+#pragma unroll
+                        for (int j = 0; j < kChainBatch; ++j) lnodes[wave][lane][j] = path[min(first_k + j, depth)];
+                        const int leaf = path[depth];
+                        const float4 l0 = bt.nodes[2 * (size_t)leaf], l1 = bt.nodes[2 * (size_t)leaf + 1];
+                        lbox0[wave][lane] = l0;
+                        lbox1[wave][lane] = make_float2(l1.x, l1.y);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
             }
             unsigned slice_pairs = 0xffffffffu;   // balanced walk of the staged part of the slice (rays and keys are in LDS anyway)
             if (VREC && WAVES <= 8 && n_lds > 0 && dbg_pairs != 0) {
@@ -1673,9 +1741,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 // pixel alone from the tile's whole list (general_winner + chain_ok_general, excluding what fails).
                 const BvhTiles& bt = *bvh;
                 const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-                const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, tly0));
-                const int first_level = __builtin_amdgcn_readfirstlane(
-                    tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[0], lane));
+                const int first_level = first_level_h;   // the tile's reference path is in lpath[0] (this wave's)
                 int tl_sample_bvh = 0;   // timeline mode: (slices done, chains checked) per sample of the first blocks' first tile
                 render_pixel<true, false, false, false, MAT>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     const V3 c1 = rot0_exact(bt.rot, d1);
@@ -1700,9 +1766,57 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     const unsigned long long kbest = best_key[lane];
                     int slot = -1;
                     bool alone = !hot;
+#ifdef CRT_DBG_NOCHAIN_HEAVY   // timing experiment only (wrong pixels where a chain fails)
                     if (hot && kbest != ~0ull) {
-                        slot = bt.partner[0x7fffffff - (int)(unsigned)(kbest & 0xffffffffull)];
-                        alone = !chain_ok(bt, slot, first_level, lpath[0], o, c1, c2, c3);
+                        const int qk0 = (int)(unsigned)(kbest & 0xffffffffull);
+                        slot = multi ? bt.partner[0x7fffffff - qk0] : lslot[(qk0 >> 6) & 7][qk0 & 63];
+                        alone = false;
+                    }
+                    if (false) {
+#else
+                    if (hot && kbest != ~0ull) {
+#endif
+                        const int qk = (int)(unsigned)(kbest & 0xffffffffull);
+                        if (multi) {   // chunked slices: the key is the tie order alone
+                            slot = bt.partner[0x7fffffff - qk];
+                            alone = !chain_ok(bt, slot, first_level, lpath[0], o, c1, c2, c3);
+                        } else {       // staged slices: the winner's wave and position are in the key
+                            const int sw = (qk >> 6) & 7, kw = qk & 63;
+                            slot = lslot[sw][kw];
+                            const int info = linfo[sw][kw];
+                            const bool inside = hit_inside_leaf_box(lbox0[sw][kw], lbox1[sw][kw], o, c3, key_t(kbest));
+                            if (__builtin_amdgcn_ballot_w64(!inside) == 0ull) {
+                                alone = false;      // every winner of this sample is reached: no node loads
+                            } else if (inside) {
+                                alone = false;
+                            } else if (info >> 16) {   // more levels than one batch: the general routine (global loads)
+                                alone = !chain_ok(bt, slot, first_level, lpath[0], o, c1, c2, c3);
+                            } else {
+                                const int depth = info & 31, first_k = (info >> 8) & 31;
+                                int node[kChainBatch];
+                                float4 na[kChainBatch], nb[kChainBatch];
+#pragma unroll
+                                for (int j = 0; j < kChainBatch; ++j) node[j] = lnodes[sw][kw][j];
+#pragma unroll
+                                for (int j = 0; j < kChainBatch; ++j) {
+                                    na[j] = bt.nodes[2 * (size_t)node[j]];
+                                    nb[j] = bt.nodes[2 * (size_t)node[j] + 1];
+                                }
+                                const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
+                                bool ok = true;
+#pragma unroll
+                                for (int j = 0; j < kChainBatch; ++j) {
+                                    const int lv = min(first_k + j, depth);
+                                    V3 d = c3, y = y3;
+                                    if (lv < 2) {
+                                        d = sel3(lv == 0, c1, c2);
+                                        y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
+                                    }
+                                    ok = ok && box_hit_fast(na[j], nb[j], o, d, y);
+                                }
+                                alone = !ok;
+                            }
+                        }
                     }
                     if (alone) {   // per lane, over the tile's whole list
                         const V3 c5 = rot0(bt.rot, unit_vector(c4));
@@ -1907,6 +2021,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 linfo[wave][lane] = depth | (first_k << 8) | ((n_lv > kChainBatch) ? (1 << 16) : 0);
 #pragma unroll
                 for (int j = 0; j < kChainBatch; ++j) lnodes[wave][lane][j] = path[min(first_k + j, depth)];
+                const int leaf = path[depth];
+                const float4 l0 = bt.nodes[2 * (size_t)leaf], l1 = bt.nodes[2 * (size_t)leaf + 1];
+                lbox0[wave][lane] = l0;
+                lbox1[wave][lane] = make_float2(l1.x, l1.y);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1941,6 +2059,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 unsigned excl = 0u, excl_hi = 0u;
                 for (bool first = true;; first = false) {
                     int q = -1;
+                    float t_win = 0.0f;   // the winner's t (the reference's rec.t): the hit point o + t * c3 decides whether the chain needs loads
                     if (first && bp != 0xffffffffu) {
                         lkey[wave][lane] = ~0ull;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1955,23 +2074,27 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         const unsigned long long kb = lkey[wave][lane];
                         q = (kb == ~0ull) ? -1 : (int)(unsigned)(kb & 0xffffffffull);
+                        t_win = key_t(kb);
                     } else {
                         Cand rest = cand;
                         rest.lo &= ~excl;
                         rest.hi &= ~excl_hi;
                         float tb = FLT_MAX;
                         trace_candidates(lrec[wave], lent[wave], rest, c3, tb, q);
+                        t_win = tb;
                     }
                     int slot = -1;
                     bool bad = false;
                     const int kw = q & 63;   // the winner's position in the staged list
-#ifdef CRT_DBG_NOCHAIN   // timing experiment only: the chain of boxes is not tested (wrong pixels where it matters)
+                    // the winner's hit point strictly inside its leaf's box: every box of its chain is passed, no loads
+                    const bool chain_sure = q >= 0 && hot && hit_inside_leaf_box(lbox0[wave][kw], lbox1[wave][kw], o, c3, t_win);
+                    const bool need_chain = q >= 0 && hot && !chain_sure;
                     if (q >= 0 && hot) slot = lslot[wave][kw];
+#ifdef CRT_DBG_NOCHAIN   // timing experiment only: the chain of boxes is not tested (wrong pixels where it matters)
                     if (false) {
 #else
-                    if (q >= 0 && hot) {
+                    if (__builtin_amdgcn_ballot_w64(need_chain) != 0ull && need_chain) {
 #endif
-                        slot = lslot[wave][kw];
                         const int info = linfo[wave][kw];
                         if (info >> 16) {   // more levels than one batch: the general routine (global loads)
                             bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
