@@ -1579,13 +1579,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const int n_src = skip_item ? 0 : (walk_all ? n_tris : (int)desc.y);
             const uint32_t* __restrict__ lst = w.pool + desc.x;
             if (timeline) tl_heavy = ((unsigned long long)(unsigned)n_src << 24) | (unsigned)tile_id;
-            // List world: the master wave (wave 0) has no slice — it runs the rejection draws of the hit branch while the
-            // other WAVES - 1 waves trace (render_pixel<.., SPEC>).  BVH world: every wave has a slice (seven slices would
-            // push the 1 800-2 000-entry pole tiles of C5 past four staging chunks per wave, i.e. to the tree walk: 10 -> 47 ms;
-            // and the draws are not what a shared BVH tile waits for — the winner's chain of boxes is).
-            constexpr int kSliceWaves = BVH ? WAVES : WAVES - 1;
-            const int swave = BVH ? wave : wave - 1;
-            const int per = (n_src + kSliceWaves - 1) / kSliceWaves;
+            // The master wave (wave 0) has no slice — it runs the rejection draws of the hit branch on a copy of the streams while
+            // the other WAVES - 1 waves trace (render_pixel<.., SPEC>) — unless (BVH world) seven slices would not fit four staging
+            // chunks of 64 each: the 1 800-2 000-entry pole tiles of C5 then take eight slices, the master tracing one itself
+            // (seven would send them to the tree walk: 10 -> 47 ms, measured in round 2).
+            const int slice_waves = (BVH && n_src > (WAVES - 1) * 256) ? WAVES : WAVES - 1;
+            const int swave = (slice_waves == WAVES) ? wave : wave - 1;
+            const int per = (n_src + slice_waves - 1) / slice_waves;
             const int k0 = (swave < 0) ? 0 : min(n_src, swave * per), k1 = (swave < 0) ? 0 : min(n_src, k0 + per);
             // Tiles with a list: the slices are INTERLEAVED (wave s takes entries s, s + 7, s + 14, ...).  Neighbours in a
             // tile's list are neighbours in the mesh and cover the same pixels; dealt round-robin, every slice gets its share
@@ -1593,7 +1593,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             // with contiguous slices the 247-entry pole tiles took 245 or 640 us depending on the order the binning's
             // atomics happened to leave the list in — and ended the launch in the second case).
             const bool interleaved = !walk_all;
-            const int cnt_w = (!interleaved || swave < 0 || swave >= n_src) ? 0 : (n_src - swave + kSliceWaves - 1) / kSliceWaves;
+            const int cnt_w = (!interleaved || swave < 0 || swave >= n_src) ? 0 : (n_src - swave + slice_waves - 1) / slice_waves;
             // local rows of the tile (tiles are 8 local rows; they never straddle a strip)
             const int hx0 = (tile_id % w.tiles_x) * 8, tly0 = (tile_id / w.tiles_x) * 8;   // tly0: the tile's first local row
             const int hly0 = tly0 + sub * sub_rows;                                         // hly0: this item's
@@ -1618,7 +1618,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             int slice_mine = 0;
             Cand cand = {0u, 0u, 0u, 0u};
             if (n_lds > 0) {   // per-pixel candidates among the staged entries of this wave's slice
-                slice_mine = (lane < n_lds) ? (int)lst[swave + lane * kSliceWaves] : 0;
+                slice_mine = (lane < n_lds) ? (int)lst[swave + lane * slice_waves] : 0;
                 stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
                                  global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
             }
@@ -1632,7 +1632,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 for (int c = 0; c < 4; ++c)
                     if (c < s_chunks) {
                         const int n = min(64, cnt_w - 64 * c);
-                        e_c[c] = (lane < n) ? (int)lst[swave + (64 * c + lane) * kSliceWaves] : 0;
+                        e_c[c] = (lane < n) ? (int)lst[swave + (64 * c + lane) * slice_waves] : 0;
                         stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, e_c[c], n, lane, x, gy, cc[c]);
                         if (!lane_valid) cc[c].lo = cc[c].hi = 0u;
                         q_c[c] = (lane < n) ? (int)(((unsigned)e_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bvh->partner[e_c[c] & 0x7fffffff])) : 0;
@@ -1716,7 +1716,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     trace_pairs(lrec[wave], lent[wave], lpairs[wave], slice_pairs, lane,
                                 [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key);
                 else if (n_lds > 0) trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
-                if (interleaved) walk_list_strided<true>(rec, lst, swave, kSliceWaves, n_lds, cnt_w, lane, d2, closest, hit_idx);
+                if (interleaved) walk_list_strided<true>(rec, lst, swave, slice_waves, n_lds, cnt_w, lane, d2, closest, hit_idx);
                 else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);   // no list: a range of all triangles
               }
             };
@@ -1743,7 +1743,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
                 const int first_level = first_level_h;   // the tile's reference path is in lpath[0] (this wave's)
                 int tl_sample_bvh = 0;   // timeline mode: (slices done, chains checked) per sample of the first blocks' first tile
-                render_pixel<true, false, false, false, MAT>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
+                render_pixel<true, false, false, !MAT, MAT>(p, x, ly, shade_n, state, rgb, lane_valid,
+                             [&](V3 d1, V3, float& closest, int& hit_idx, auto&&... hit_branch_draws) {
                     const V3 c1 = rot0_exact(bt.rot, d1);
                     const V3 c2 = chain_next<true>(bt.rot, c1);
                     const V3 c3 = chain_next<true>(bt.rot, c2);
@@ -1756,10 +1757,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     ray_d[2][lane] = c3.z;
                     best_key[lane] = ~0ull;
                     __syncthreads();   // B1
-                    int q = -1;
-                    float tb = FLT_MAX;
-                    trace_slice(c3, tb, q);
-                    if (q >= 0) atomicMin(&best_key[lane], hit_key(tb, q));
+                    if (swave >= 0) {   // eight slices: the master traces one too
+                        int q = -1;
+                        float tb = FLT_MAX;
+                        trace_slice(c3, tb, q);
+                        if (q >= 0) atomicMin(&best_key[lane], hit_key(tb, q));
+                    }
+                    (hit_branch_draws(), ...);   // one Lambertian: the hit branch's draws on a copy of the stream, while the other waves trace
                     __syncthreads();   // B2
                     if (timeline && blockIdx.x < (unsigned)kStatsSampleBlocks && lane == 0 && tl_sample_bvh < kStatsSampleSlots)
                         stats_in[kStatsSampleLog + (blockIdx.x * kStatsSampleSlots + tl_sample_bvh) * 2 + 0] = (unsigned long long)wall_clock64();   // slices done
