@@ -556,7 +556,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 #ifndef CRT_VGPR_CAM
 #define CRT_VGPR_CAM 1   // measured on the bench frame: shade 0.816 -> 0.769 ms (profiles/r2_tiled/sweep_occ.txt)
 #endif
-    const bool kVgprCam = FASTDIV && CRT_VGPR_CAM;   // experiment: ray set-up constants in VGPRs (see in_vgpr)
+    const bool kVgprCam = FASTDIV && CRT_VGPR_CAM && WANT_D2;   // ray set-up constants in VGPRs (see in_vgpr); not in the BVH mode (WANT_D2 false), whose kernel is short of registers as it is
     const float fnx = kVgprCam ? in_vgpr((float)p.nx) : (float)p.nx, fny = kVgprCam ? in_vgpr((float)p.ny) : (float)p.ny;
     const float rnx = kVgprCam ? in_vgpr(p.rnx) : p.rnx, rny = kVgprCam ? in_vgpr(p.rny) : p.rny;
     CameraPOD cv = c;
