@@ -1612,6 +1612,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             // (from the LONGEST slice, `per`: the mode must be the same for every wave of the block — the waves of a tree tile
             // skip the per-sample barriers the others wait at; a wave with a shorter slice just stages fewer entries)
             const int s_chunks = (BVH && !walk_all) ? (min(per, n_src) + 63) / 64 : 1;
+            // (the candidate masks and entries of the up to four chunks are what this kernel spills: without the chunked mode it has
+            // 116 B of scratch per lane instead of 332 — and the same C3 frame time, 1.18 ms, while C5's pole tiles would walk the
+            // tree: 95 ms.  Measured, kept.)
             const bool tree_tile = BVH && (walk_all || s_chunks > 4 || !VREC);
             const bool multi = BVH && !tree_tile && s_chunks > 1;
             const int n_lds = (VREC && !walk_all && !multi && !tree_tile) ? min(64, cnt_w) : 0;
