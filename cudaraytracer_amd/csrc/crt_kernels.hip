@@ -690,17 +690,23 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
     colz = (colz > 1.0f) ? 1.0f : ((colz < 0.0f) ? 0.0f : colz);
 
     if (!store) return;
-    const size_t o = ((size_t)ly * p.nx + x) * 3;
+    // The addresses of the stores are formed HERE, from copies of x and ly the compiler cannot trace back (an empty asm):
+    // left alone it keeps the 64-bit addresses it formed for the loads at the top alive across the whole sample loop —
+    // three VGPR pairs the kernel does not have at six waves per SIMD and spills, per tile (46 MB of scratch writes per frame).
+    int x_st = x, ly_st = ly;
+    asm volatile("" : "+v"(x_st), "+v"(ly_st));
+    const long long si_st = (long long)ly_st * p.nx + x_st;
+    const size_t o = (size_t)si_st * 3;
     rgb[o + 0] = colx;
     rgb[o + 1] = coly;
     rgb[o + 2] = colz;
 
-    state[0 * stride + si] = rs.d;
-    state[1 * stride + si] = rs.v0;
-    state[2 * stride + si] = rs.v1;
-    state[3 * stride + si] = rs.v2;
-    state[4 * stride + si] = rs.v3;
-    state[5 * stride + si] = rs.v4;
+    state[0 * stride + si_st] = rs.d;
+    state[1 * stride + si_st] = rs.v0;
+    state[2 * stride + si_st] = rs.v1;
+    state[3 * stride + si_st] = rs.v2;
+    state[4 * stride + si_st] = rs.v3;
+    state[5 * stride + si_st] = rs.v4;
 }
 
 // The `render` kernel for a pixel of a tile WITHOUT survivors: every sample is background
@@ -795,10 +801,13 @@ __device__ __forceinline__ void render_sky_pixel_impl(const RenderParams& p, int
     colx = (colx > 1.0f) ? 1.0f : ((colx < 0.0f) ? 0.0f : colx);        // clip, vec3.h:119-131
     coly = (coly > 1.0f) ? 1.0f : ((coly < 0.0f) ? 0.0f : coly);
     colz = (colz > 1.0f) ? 1.0f : ((colz < 0.0f) ? 0.0f : colz);
-    const size_t o = ((size_t)ly * p.nx + x) * 3;
+    int x_st = x, ly_st = ly;                                          // store addresses formed here (see render_pixel)
+    asm volatile("" : "+v"(x_st), "+v"(ly_st));
+    const long long si_st = (long long)ly_st * p.nx + x_st;
+    const size_t o = (size_t)si_st * 3;
     rgb[o + 0] = colx; rgb[o + 1] = coly; rgb[o + 2] = colz;
-    state[0 * stride + si] = rs.d; state[1 * stride + si] = rs.v0; state[2 * stride + si] = rs.v1;
-    state[3 * stride + si] = rs.v2; state[4 * stride + si] = rs.v3; state[5 * stride + si] = rs.v4;
+    state[0 * stride + si_st] = rs.d; state[1 * stride + si_st] = rs.v0; state[2 * stride + si_st] = rs.v1;
+    state[3 * stride + si_st] = rs.v2; state[4 * stride + si_st] = rs.v3; state[5 * stride + si_st] = rs.v4;
 }
 
 __device__ __forceinline__ void render_sky_pixel(const RenderParams& p, int x, int ly, uint32_t* __restrict__ state,
