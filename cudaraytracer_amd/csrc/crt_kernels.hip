@@ -1929,10 +1929,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     // The light classes form one list, most survivors first; chunk k of kLightChunks owns the
     // items k, k + 64, k + 128, ... and has its own cursor (own cache line).  A wave works
     // through "its" chunk and then helps with whatever chunk still has tiles.
+    // (bits 30..31 of split_packed: light tiles WITH geometry are dealt out as 1 << lsl row slabs too — for launches with far
+    // more waves than such tiles, where one wave's 64-sample chain over a whole tile is the longest thing left; list world)
+    const unsigned lsl = BVH ? 0u : (split_packed >> 30) & 3u;
     unsigned light_len[kLightClasses], n_light = 0;
 #pragma unroll
     for (int c = 0; c < kLightClasses; ++c) {
-        light_len[c] = w.counters[kCtrQueueLen + kHeavyClasses + c];
+        light_len[c] = w.counters[kCtrQueueLen + kHeavyClasses + c] << ((c < kLightClasses - 1) ? lsl : 0u);
         n_light += light_len[c];
     }
     // Items are dealt to the chunks in groups of kLightGroup consecutive queue positions: within a class the
@@ -1972,7 +1975,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 #pragma unroll
         for (int c = 0; c < kLightClasses - 1; ++c)
             if (lc == c && item >= light_len[c]) { item -= light_len[c]; lc = c + 1; }
-        const int tile_id = __builtin_amdgcn_readfirstlane((int)w.queue[(size_t)(kHeavyClasses + lc) * w.tiles_total + item]);
+        const unsigned isl = (lc < kLightClasses - 1) ? lsl : 0u;   // this item: slab `sub` of 1 << isl of its tile
+        const int sub = (int)(item & ((1u << isl) - 1u)), sub_rows = 8 >> isl;
+        const int tile_id = __builtin_amdgcn_readfirstlane((int)w.queue[(size_t)(kHeavyClasses + lc) * w.tiles_total + (item >> isl)]);
         const uint2 desc = w.tile_desc[tile_id];
         const int cnt = __builtin_amdgcn_readfirstlane((int)desc.y);
 #if CRT_PRIO
@@ -1981,6 +1986,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         const uint32_t* __restrict__ lst = w.pool + __builtin_amdgcn_readfirstlane(desc.x);
         const int x0 = (tile_id % w.tiles_x) * 8, ly0 = (tile_id / w.tiles_x) * 8;
         const int x = x0 + (lane & 7), ly = ly0 + (lane >> 3);
+        // this item's pixels: on the image and inside its slab of rows (every other lane replays a pixel, unstored, without candidates)
+        const bool lane_ok = x < p.nx && ly < p.row_count && (lane >> 3) >= sub * sub_rows && (lane >> 3) < (sub + 1) * sub_rows;
         // the whole list of a light tile fits one or two VGPRs (lane j holds positions j, 64+j)
         const int mine0 = (lane < cnt) ? (int)lst[lane] : 0;
         const int mine1 = (64 + lane < cnt) ? (int)lst[64 + lane] : 0;
@@ -2178,7 +2185,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         // as (ordered t, index) keys (atomicMin = the reference's accept rule).
         unsigned n_pairs = 0xffffffffu;
         if (VREC && WAVES <= 8 && cnt > 0 && dbg_pairs != 0) {
-            if (!(x < p.nx && ly < p.row_count)) cand.lo = cand.hi = 0u;   // lanes off the image replay a pixel: no pairs of their own
+            if (!lane_ok) cand.lo = cand.hi = 0u;   // lanes off the image replay a pixel: no pairs of their own
             n_pairs = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
         }
         const bool pair_mode = n_pairs != 0xffffffffu;
@@ -2187,9 +2194,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             else atomicAdd(&stats[41], 1ull);
         }
         if (cnt == 0) {   // background only (most tiles of a typical frame)
-            if (x < p.nx && ly < p.row_count) render_sky_pixel(p, x, ly, state, rgb);
+            if (lane_ok) render_sky_pixel(p, x, ly, state, rgb);
         } else if (pair_mode) {   // all 64 lanes stay active (ds_bpermute reads lanes); off-image lanes replay a valid pixel, unstored
-            render_pixel<true, false, true, false, MAT>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, x < p.nx && ly < p.row_count,
+            render_pixel<true, false, true, false, MAT>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, lane_ok,
                          [&](V3, V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 lkey[wave][lane] = ~0ull;
@@ -2208,7 +2215,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 closest = 0.0f;   // not used after the traversal
               }
             }, mv);
-        } else if (x < p.nx && ly < p.row_count) {
+        } else if (lane_ok) {
             render_pixel<true, false, true, false, MAT>(p, x, ly, shade_n, state, rgb, true,
                          [&](V3, V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
@@ -2457,6 +2464,10 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     // shared tiles are tested without slabs).  The mechanism stays for the tuning build (CRT_SPLIT).
     int split[kHeavyClasses] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (d_bvh_tiles == nullptr) split[0] = 2;
+    // ... and for launches with few tiles per CU (one rank's strips of an 8-way split), together with two slabs per light tile
+    // that holds geometry (light_split below): slowest rank 0.309 -> 0.280 ms on C3, 0.407 -> 0.374 ms on C3B
+    // (profiles/r3_tiled/sweep_light_split_*.txt) — the machine is idle enough there for the replicated ray set-up not to matter
+    if (d_bvh_tiles == nullptr && tiles_per_cu < 24) { split[1] = split[2] = split[3] = split[4] = split[5] = 2; split[6] = 1; }
     if (variant == 5)   // test hook (crt_set_kernel_variant(10)): shared tiles from 4 entries on, dealt out as 2, 4 or 8 row slabs by class
         for (int c = 0; c < kHeavyClasses; ++c) split[c] = 1 + c % 3;
 #ifdef CRT_TUNING
@@ -2473,6 +2484,14 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* e = getenv("CRT_LIGHT_GROUP")) light_group = (unsigned)std::max(1, std::min(atoi(e), 7));
 #endif
     split_packed |= light_group << 27;
+    // light tiles with geometry as row slabs (bits 30..31): small launches only, list world (shade_tiles_kernel)
+    unsigned light_split = (d_bvh_tiles == nullptr && tiles_per_cu < 24) ? 1u : 0u;
+    if (variant == 5) light_split = 2u;   // test hook (crt_set_kernel_variant(10))
+#ifdef CRT_TUNING
+    if (const char* e = getenv("CRT_LIGHT_SPLIT")) light_split = (unsigned)std::max(0, std::min(atoi(e), 3));
+#endif
+    if (d_bvh_tiles != nullptr) light_split = 0u;
+    split_packed |= light_split << 30;
     ShadeFn fn;
     if (group == 4) {   // experiment (CRT_SHADE_GROUP=4): half as many waves parked per shared tile, more blocks free for light tiles at once
         occ = 6;
