@@ -83,6 +83,7 @@ void free_context_memory(Context* c) {   // device memory and events of a contex
     if (c->w.queue) (void)hipFree(c->w.queue);
     if (c->w.tile_count) (void)hipFree(c->w.tile_count);
     if (c->w.counters) (void)hipFree(c->w.counters);
+    if (c->d_pixel_queue) (void)hipFree(c->d_pixel_queue);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
@@ -943,13 +944,18 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         float rot[9];
         rotation_zero_matrix(rot);
         const crt_bvh* t = world == 1 ? scene->bvh : nullptr;
+        if (!cx.d_pixel_queue) HIP_TRY(hipMalloc(&cx.d_pixel_queue, 64));
+        if (!cx.n_cus) HIP_TRY(hipDeviceGetAttribute(&cx.n_cus, hipDeviceAttributeMultiprocessorCount, cx.device));
         HIP_TRY(crt::launch_render_generic(p, t ? t->d_base_slots : scene->d_base, t ? t->d_shade_n_slots : scene->d_shade_n,
                                            t ? t->d_material_slots : scene->d_material_of, scene->d_materials, scene->n_tris,
                                            t ? t->d_nodes : nullptr, t ? t->n_nodes : 0, rot, rng->d_state, d_rgb, world == 1, fast,
                                            shader, max_depth, force_mode, stream,
                                            // pair records for the incoherent secondary rays of `shade`; primary rays of one tile walk the
-                                           // same nodes and are a little faster over the skip links (variant 9: skip links everywhere)
-                                           (t && shader == CRT_SHADER_SHADE && g_variant != 9) ? t->d_pairs : nullptr, t ? t->d_partner : nullptr));
+                                           // same nodes and are a little faster over the skip links (variant 9: skip links everywhere;
+                                           // 11: one stack per lane; 12: the shared walk with a short list)
+                                           (t && shader == CRT_SHADER_SHADE) ? t->d_pairs : nullptr, t ? t->d_partner : nullptr,
+                                           g_variant == 9 ? 0 : (g_variant == 11 ? 1 : (g_variant == 12 ? 3 : 2)),
+                                           cx.d_pixel_queue, cx.n_cus, g_d_stats));
         cx.ev_has_mid = false;
         if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
         cx.ev_valid = timing;

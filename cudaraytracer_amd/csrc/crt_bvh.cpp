@@ -281,7 +281,8 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
     // the normal cones are static, the boxes are copied from the flat nodes on the device (after this upload and after every refit)
     std::vector<float4> pairs;
     std::vector<int> pair_flat;
-    if (b.max_depth + 1 <= crt::kPairStackDepth) {   // one stack entry per level (bvh_walk_pairs)
+    // one stack entry per level (bvh_walk_pairs); 23 bits of slot and 24 of pair index in the items of the shared walk (bvh_walk_coop)
+    if (b.max_depth + 1 <= crt::kPairStackDepth && n <= (1 << 23)) {
         std::vector<int> pair_of((size_t)t->n_nodes, -1), first_slot((size_t)t->n_nodes + 1, n);
         int n_inner = 0;
         for (int i = 0; i < t->n_nodes; ++i)

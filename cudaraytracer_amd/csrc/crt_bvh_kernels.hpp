@@ -44,7 +44,26 @@ struct BvhView {
     // null: the walks below use `nodes` only.
     const float4* pairs = nullptr;
     const int* partner = nullptr;   // BvhTiles::partner: the tie order as one key (larger wins among equal t)
+#ifdef CRT_TUNING
+    // tuning builds (crt_debug_tiled_stats around a generic-kernel launch): [0] trips [1] lanes in flight [2] walk steps
+    // [3] lanes walking [4] rounds of triangle tests [5] lanes testing
+    unsigned long long* walk_stats = nullptr;
+    bool walk_count = false;   // set by the kernel: counters (stats mode 1), not only the time stamps (mode 2)
+    unsigned* wave_steps = nullptr;   // set by the kernel (LDS): this wavefront's walk steps, for its timeline record
+#endif
 };
+#ifdef CRT_TUNING
+__device__ __forceinline__ void walk_stat(const BvhView& b, int word, unsigned long long mask) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (word == 2 && b.wave_steps && lane == __builtin_amdgcn_readfirstlane(lane)) ++*b.wave_steps;
+    if (b.walk_count && lane == __builtin_amdgcn_readfirstlane(lane)) {   // the first ACTIVE lane
+        atomicAdd(&b.walk_stats[word], 1ull);
+        atomicAdd(&b.walk_stats[word + 1], (unsigned long long)__builtin_popcountll(mask));
+    }
+}
+#else
+#define walk_stat(b, word, mask) ((void)0)
+#endif
 
 // kPairStackDepth (crt_device.hpp): pending right children per lane (LDS); deeper trees take the skip-link walk
 
@@ -264,6 +283,20 @@ __device__ __forceinline__ void pair_leaf(const BvhView& b, const float* __restr
 // stack with two entries per level halves the resident blocks of the generic kernel, and that costs more (shade 19.8 ->
 // 26.9 ms) than the second record in flight gains.  Returns false for a lane that ran out of stack (the caller walks it
 // again with the general loop; the host only builds pair records for trees that fit).
+//
+// The triangles of hit leaves are NOT tested where they are found: with 64 lanes at 64 different nodes almost every trip
+// has some lane at a leaf, and the triangle code (the larger half of a trip) ran for a handful of lanes each time — 20 of
+// 64 lanes active per VALU cycle over the whole kernel (tools/pmc_lanes.sh).  A lane queues its triangles (slot + which
+// chain element they see) at the top of its stack area and walks on; the wavefront tests queued triangles together, one
+// per lane and round, when most lanes hold some (or a lane's area runs short, or the walk has ended).  Nothing observable
+// depends on the order of the tests: every box-hit leaf is tested whatever has been found so far (the reference has no
+// culling by the closest hit) and the merge rule below is a total order on (t, partner).
+#ifndef CRT_DRAIN_HI
+#define CRT_DRAIN_HI 40   // start a round of triangle tests when this many lanes hold queued triangles ...
+#endif
+#ifndef CRT_DRAIN_LO
+#define CRT_DRAIN_LO 24   // ... and go on while this many still do
+#endif
 template <bool PRIMARY = true>
 __device__ __forceinline__ bool bvh_walk_pairs(const BvhView& b, const float* __restrict__ rec, V3 o, V3 c1, const PairDirs& pd, bool take,
                                                int* __restrict__ stack, int stack_stride, float& best_t, int& best_slot, V3& dir_used) {
@@ -279,10 +312,28 @@ __device__ __forceinline__ bool bvh_walk_pairs(const BvhView& b, const float* __
         }
     }
     int cur = 0, sp = 0, depth = 0;   // depth of the pair's node: its children's boxes see k = depth + 2, a leaf child's triangles k = depth + 4
+    int nq = 0;                       // queued triangles: stack[(kPairArea - 1 - j) * stride], j < nq
     // ONE loop with a wave-uniform condition; a lane that has run out of nodes is masked, the others go on.  (Written as a
     // per-lane `for (;;)` with break / pop branches the compiler nests the loops, and a lane that needs to pop waits for
     // every other lane of the wavefront to reach a dead end: 2x slower than the skip links, measured.)
-    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+    for (;;) {
+        const bool walking = __builtin_amdgcn_ballot_w64(alive) != 0ull;
+        // a trip needs room for one stack entry and four triangles; a lane without queue always has it (kPairArea - kPairStackDepth >= 5)
+        int go_on = walking ? CRT_DRAIN_HI : 1;
+        for (;;) {
+            const unsigned long long pending = __builtin_amdgcn_ballot_w64(nq > 0);
+            const unsigned long long tight = __builtin_amdgcn_ballot_w64(nq > 0 && sp + nq > kPairArea - 5);
+            if (tight == 0ull && __builtin_popcountll(pending) < go_on) break;
+            walk_stat(b, 4, pending);
+            if (nq > 0) {
+                --nq;
+                const int item = stack[(kPairArea - 1 - nq) * stack_stride];
+                pair_tri<PRIMARY>(b, rec, item & 0xffffff, o, sel3((item & 0x40000000) != 0, pd.c3, pd.c4), best_t, best_slot, dir_used);
+            }
+            go_on = walking ? CRT_DRAIN_LO : 1;
+        }
+        if (!walking) break;
+        walk_stat(b, 2, __builtin_amdgcn_ballot_w64(alive));
         if (alive) {
             const float4* __restrict__ pr = b.pairs + 4 * (size_t)cur;
             const float4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
@@ -296,8 +347,23 @@ __device__ __forceinline__ bool bvh_walk_pairs(const BvhView& b, const float* __
             // a child whose subtree's stored normals ALL have d . n < 0 beyond rounding holds no triangle that passes the
             // first test of Triangle::collision_detection (triangle.h:61): it is skipped like a missed box
             const bool try_l = hit_l && !cone_rejects(__float_as_uint(p3.z), dt), try_r = hit_r && !cone_rejects(__float_as_uint(p3.w), dt);
-            if (try_l && ref_l < 0) pair_leaf<PRIMARY>(b, rec, ref_l, o, dt, best_t, best_slot, dir_used);
-            if (try_r && ref_r < 0) pair_leaf<PRIMARY>(b, rec, ref_r, o, dt, best_t, best_slot, dir_used);
+            const int flag = tri3 ? 0x40000000 : 0;
+            if (try_l && ref_l < 0) {   // a leaf: 1 or 2 triangles (bvh.h:95-109)
+                stack[(kPairArea - 1 - nq) * stack_stride] = (ref_l & 0xffffff) | flag;
+                ++nq;
+                if (((ref_l >> 24) & 3) == 2) {
+                    stack[(kPairArea - 1 - nq) * stack_stride] = ((ref_l & 0xffffff) + 1) | flag;
+                    ++nq;
+                }
+            }
+            if (try_r && ref_r < 0) {
+                stack[(kPairArea - 1 - nq) * stack_stride] = (ref_r & 0xffffff) | flag;
+                ++nq;
+                if (((ref_r >> 24) & 3) == 2) {
+                    stack[(kPairArea - 1 - nq) * stack_stride] = ((ref_r & 0xffffff) + 1) | flag;
+                    ++nq;
+                }
+            }
             const bool go_l = try_l && ref_l >= 0, go_r = try_r && ref_r >= 0;
             ++depth;
             if (go_l && go_r) {

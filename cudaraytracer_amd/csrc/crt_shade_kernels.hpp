@@ -58,15 +58,229 @@ __device__ __forceinline__ void list_trace_any(const ShadeScene& sc, V3 o, V3 d1
     }
 }
 
+
+// ---- the pair walk, shared by the wavefront -------------------------------------------------------------------
+// With one ray per lane and a private stack (bvh_walk_pairs) a trip lasts as long as the LONGEST walk of its 64 rays —
+// 195 steps for rays inside the mesh where the mean is 30 — with 28 of 64 lanes walking (tools/walk_stats.py), and a
+// pixel behind glass needs 36 such trips one after the other: the launch waited 10 ms for those chains with the chip
+// idle.  Here the wavefront's rays sit in LDS and the WORK is shared: two lists per wavefront, node items (ray, pair
+// record) and triangle items (ray, slot); every round the 64 lanes take the 64 newest items of one list, whichever rays
+// they belong to, and push what the tests yield.  A trip lasts (sum of its rays' steps) / 64 rounds, the last ray of a
+// pixel gets all 64 lanes.  Nothing observable depends on the order: every leaf whose box and whose ancestors' boxes
+// are hit is tested, each with the direction of its depth (the reference has no culling by the closest hit), and the
+// results meet in one 64-bit key per ray under atomicMin — smallest t, among equal t the larger partner (bvh_walk_pairs'
+// merge rule, a total order).
+constexpr int kCoopNodeCap = 1024;   // node items per wavefront (newest first: at most 64 per level of the tree pending — more: the trip is redone by the literal walk)
+constexpr int kCoopTriCap = 320;     // triangle items: fewer than 64 before a round of nodes, at most 4 more per lane
+constexpr int kCoopRayVecs = 5;      // float4 per ray: (o, cyc) c3 y3 c4 y4
+constexpr int kCoopWaveBytes = 64 * kCoopRayVecs * 16 + 64 * 8 + kCoopNodeCap * 4 + kCoopTriCap * 4;
+struct CoopLds {
+    float4* rays;                // [64][kCoopRayVecs]
+    unsigned long long* best;    // [64] (ordered t, tie order) keys
+    unsigned* nodes;             // [cap]  ray << 26 | class << 24 | pair index
+    unsigned* tris;              // [kCoopTriCap]  ray << 26 | sees c3 << 25 | place in its leaf << 23 | slot
+    int cap;                     // kCoopNodeCap (a test variant: 96, so that trips are abandoned)
+};
+struct PairStep {                // what one pair record yields for one ray
+    bool go_l = false, go_r = false;   // inner children to follow
+    int ref_l = 0, ref_r = 0;
+    int cnt_l = 0, cnt_r = 0;          // triangles of hit leaf children (0: not a leaf, or missed)
+};
+__device__ __forceinline__ PairStep pair_step(const BvhView& b, int cur, V3 o, V3 d, V3 y, V3 dt) {
+    const float4* __restrict__ pr = b.pairs + 4 * (size_t)cur;
+    const float4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+    const bool hit_l = box_hit_fast(p0, make_float4(p1.x, p1.y, 0.0f, 0.0f), o, d, y);
+    const bool hit_r = box_hit_fast(make_float4(p1.z, p1.w, p2.x, p2.y), make_float4(p2.z, p2.w, 0.0f, 0.0f), o, d, y);
+    PairStep s;
+    s.ref_l = __float_as_int(p3.x);
+    s.ref_r = __float_as_int(p3.y);
+    // normal cones as in bvh_walk_pairs: a child none of whose triangles can pass triangle.h:61 is skipped like a missed box
+    const bool try_l = hit_l && !cone_rejects(__float_as_uint(p3.z), dt), try_r = hit_r && !cone_rejects(__float_as_uint(p3.w), dt);
+    s.go_l = try_l && s.ref_l >= 0;
+    s.go_r = try_r && s.ref_r >= 0;
+    s.cnt_l = (try_l && s.ref_l < 0) ? ((s.ref_l >> 24) & 3) : 0;
+    s.cnt_r = (try_r && s.ref_r < 0) ? ((s.ref_r >> 24) & 3) : 0;
+    return s;
+}
+__device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+// the whole wavefront: lanes without an item pass an empty PairStep
+__device__ __forceinline__ void coop_push(const CoopLds& L, unsigned ray, unsigned child_class, bool tri3, const PairStep& s, unsigned& nn, unsigned& nt) {
+    const unsigned long long ml = __builtin_amdgcn_ballot_w64(s.go_l), mr = __builtin_amdgcn_ballot_w64(s.go_r);
+    const unsigned head = (ray << 26) | (child_class << 24);
+    if (s.go_r) L.nodes[nn + lanes_below(mr)] = head | (unsigned)s.ref_r;
+    const unsigned nr = (unsigned)__builtin_popcountll(mr);
+    if (s.go_l) L.nodes[nn + nr + lanes_below(ml)] = head | (unsigned)s.ref_l;
+    nn += nr + (unsigned)__builtin_popcountll(ml);
+    const int c = s.cnt_l + s.cnt_r;   // 0..4
+    const unsigned long long b0 = __builtin_amdgcn_ballot_w64((c & 1) != 0), b1 = __builtin_amdgcn_ballot_w64((c & 2) != 0),
+                             b2 = __builtin_amdgcn_ballot_w64((c & 4) != 0);
+    unsigned at = nt + lanes_below(b0) + 2u * lanes_below(b1) + 4u * lanes_below(b2);
+    const unsigned thead = (ray << 26) | (tri3 ? 1u << 25 : 0u);
+    if (s.cnt_l >= 1) L.tris[at++] = thead | (s.cnt_l == 2 ? 1u << 23 : 0u) | (unsigned)(s.ref_l & 0x7fffff);
+    if (s.cnt_l == 2) L.tris[at++] = thead | (2u << 23) | (unsigned)((s.ref_l & 0x7fffff) + 1);
+    if (s.cnt_r >= 1) L.tris[at++] = thead | (s.cnt_r == 2 ? 1u << 23 : 0u) | (unsigned)(s.ref_r & 0x7fffff);
+    if (s.cnt_r == 2) L.tris[at++] = thead | (2u << 23) | (unsigned)((s.ref_r & 0x7fffff) + 1);
+    nt += (unsigned)__builtin_popcountll(b0) + 2u * (unsigned)__builtin_popcountll(b1) + 4u * (unsigned)__builtin_popcountll(b2);
+}
+__device__ __forceinline__ void coop_sync() {   // LDS traffic between the lanes of ONE wavefront
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Called by ALL lanes of the wavefront.  `take`: this lane has a ray for this walk (ordinary components, chain served by
+// PairDirs).  Returns false when the node list ran full: no lane has a result then (the caller walks the rays one by one).
+template <bool PRIMARY>
+__device__ __forceinline__ bool bvh_walk_coop(const BvhView& b, const float* __restrict__ rec, V3 o, V3 c1, const PairDirs& pd, bool take,
+                                              const CoopLds& L, float& best_t, int& best_slot, V3& dir_used) {
+    const unsigned lane = lanes_below(~0ull);
+    bool alive = take;
+    {   // the root: its own box sees c1 (depth 0, k = 1); a one-leaf tree has no pair records and does not come here
+        const float4 n0 = b.nodes[0], n1 = b.nodes[1];
+        const V3 y1 = V3{reciprocal<true>(c1.x), reciprocal<true>(c1.y), reciprocal<true>(c1.z)};
+        alive = alive && box_hit_fast(n0, n1, o, c1, y1);
+    }
+    if (take) {
+        float4* r = L.rays + lane * kCoopRayVecs;
+        r[0] = make_float4(o.x, o.y, o.z, pd.cyc ? 1.0f : 0.0f);
+        r[1] = make_float4(pd.c3.x, pd.c3.y, pd.c3.z, 0.0f);
+        r[2] = make_float4(pd.y3.x, pd.y3.y, pd.y3.z, 0.0f);
+        r[3] = make_float4(pd.c4.x, pd.c4.y, pd.c4.z, 0.0f);
+        r[4] = make_float4(pd.y4.x, pd.y4.y, pd.y4.z, 0.0f);
+    }
+    L.best[lane] = ~0ull;
+    unsigned nn = 0, nt = 0;   // wave-uniform list lengths
+    {   // the root's record by the rays' own lanes, from registers: its children's boxes see c2 (k = 2), triangles of a leaf child k = 4
+        PairStep s;
+        if (alive) s = pair_step(b, 0, o, pd.c2, pd.y2, pd.c4);
+        coop_push(L, lane, 1u, false, s, nn, nt);
+    }
+    coop_sync();
+    bool ok = true;
+    while (nn != 0u || nt != 0u) {
+        if (nt >= 64u || nn == 0u) {   // a round of triangles
+            const unsigned n = min(nt, 64u);
+            nt -= n;
+            walk_stat(b, 4, __builtin_amdgcn_ballot_w64(lane < n));
+            if (lane < n) {
+                const unsigned item = L.tris[nt + lane];
+                const unsigned ray = item >> 26, slot = item & 0x7fffffu, place = (item >> 23) & 3u;
+                const bool tri3 = (item & (1u << 25)) != 0u;
+                const float4 ro = L.rays[ray * kCoopRayVecs], rd = L.rays[ray * kCoopRayVecs + (tri3 ? 1 : 3)];
+                float t;
+                if (tri_hit_lane<true, PRIMARY>(rec, (int)slot, V3{ro.x, ro.y, ro.z}, V3{rd.x, rd.y, rd.z}, t) && t < FLT_MAX) {   // hitable_list.h:84 against t_max = FLT_MAX
+                    // BvhTiles::partner without the table: a leaf of two triangles swaps them, a single one is its own
+                    const unsigned partner = place == 0u ? slot : (place == 1u ? slot + 1u : slot - 1u);
+                    atomicMin(&L.best[ray], hit_key(t, (int)(((0xffffffu - partner) << 3) | (place << 1) | (tri3 ? 1u : 0u))));
+                }
+            }
+        } else {                        // a round of pair records
+            const unsigned n = min(nn, 64u);
+            if (nn + n > (unsigned)L.cap) {
+                ok = false;
+                break;
+            }
+            nn -= n;
+            walk_stat(b, 2, __builtin_amdgcn_ballot_w64(lane < n));
+            PairStep s;
+            unsigned ray = 0u, child_class = 2u;
+            bool tri3 = false;
+            if (lane < n) {
+                const unsigned item = L.nodes[nn + lane];
+                ray = item >> 26;
+                const unsigned cls = (item >> 24) & 3u;   // 1: depth 1 (k = 3)   2: even depth >= 2   3: odd depth >= 3
+                const float4 ro = L.rays[ray * kCoopRayVecs];
+                const bool cyc = ro.w != 0.0f;
+                const bool odd = cls != 2u;                // k = depth + 2 is odd
+                const bool box3 = cls == 1u || (cyc && odd);   // pair_uses_c3
+                tri3 = cyc && odd;                             // the triangles of a leaf child see k + 2
+                const float4 rd = L.rays[ray * kCoopRayVecs + (box3 ? 1 : 3)], ry = L.rays[ray * kCoopRayVecs + (box3 ? 2 : 4)];
+                const float4 rt = L.rays[ray * kCoopRayVecs + (tri3 ? 1 : 3)];
+                s = pair_step(b, (int)(item & 0xffffffu), V3{ro.x, ro.y, ro.z}, V3{rd.x, rd.y, rd.z}, V3{ry.x, ry.y, ry.z}, V3{rt.x, rt.y, rt.z});
+                child_class = cls == 2u ? 3u : 2u;
+            }
+            coop_push(L, ray, child_class, tri3, s, nn, nt);
+        }
+        coop_sync();
+    }
+    coop_sync();
+    if (ok && take) {
+        const unsigned long long key = L.best[lane];
+        if (key != ~0ull) {
+            const unsigned low = (unsigned)key, place = (low >> 1) & 3u, partner = 0xffffffu - (low >> 3);
+            const unsigned slot = place == 0u ? partner : (place == 1u ? partner - 1u : partner + 1u);
+            const V3 dt = sel3((low & 1u) != 0u, pd.c3, pd.c4);
+            float t = FLT_MAX;
+            (void)tri_hit_lane<true, PRIMARY>(rec, (int)slot, o, dt, t);   // the winner's own t, bit for bit (the key folds -0 into +0)
+            best_t = t;
+            best_slot = (int)slot;
+            dir_used = dt;
+        }
+    }
+    coop_sync();   // the next walk rewrites rays and keys
+    return ok;
+}
+
+// bvh_trace (crt_bvh_kernels.hpp) for the shared walk: called by all lanes; `active`: this lane has a ray.
+template <bool FAST>
+__device__ __forceinline__ void bvh_trace_coop(const BvhView& b, const float* __restrict__ rec, V3 o, V3 d1, int force_mode, bool active,
+                                               const CoopLds& L, float& best_t, int& best_slot, V3& dir_used) {
+    const V3 c1 = rot0_exact(b.rot, d1);
+    const V3 c2 = chain_next<FAST>(b.rot, c1);
+    const V3 c3 = chain_next<FAST>(b.rot, c2);
+    const V3 c4 = chain_next<FAST>(b.rot, c3);
+    best_t = FLT_MAX;
+    best_slot = -1;
+    dir_used = c3;
+    const bool fixed3 = same_bits(c4, c3);
+    bool ordinary = FAST && force_mode == 0;   // every component at least 2^-40 in magnitude (and finite), the origin in the fast division's range
+    if (ordinary) {
+        const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
+                               fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
+        ordinary = lo >= 9.094947017729282e-13f && fminf(fminf(fabsf(c4.x), fabsf(c4.y)), fabsf(c4.z)) >= 9.094947017729282e-13f;
+        const float ax = fabsf(o.x), ay = fabsf(o.y), az = fabsf(o.z);
+        ordinary = ordinary && (ax == 0.0f || ax >= 1.3877787807814457e-17f) && (ay == 0.0f || ay >= 1.3877787807814457e-17f) &&
+                   (az == 0.0f || az >= 1.3877787807814457e-17f) && fmaxf(fmaxf(ax, ay), az) <= 1099511627776.0f;
+    }
+    V3 c5 = c4;
+    int mode = 0;
+    if (__builtin_amdgcn_ballot_w64(active && !fixed3) != 0ull || force_mode != 0) {
+        c5 = chain_next<FAST>(b.rot, c4);
+        mode = fixed3 ? 0 : (same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2));
+    }
+    if (force_mode == 2) mode = 2;   // test hook: every lane iterates F from c4 (must give the same pixels)
+    PairDirs pd;
+    pd.c2 = c2; pd.c3 = c3; pd.c4 = c4;
+    pd.y2 = V3{reciprocal<true>(c2.x), reciprocal<true>(c2.y), reciprocal<true>(c2.z)};
+    pd.y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
+    pd.y4 = V3{reciprocal<true>(c4.x), reciprocal<true>(c4.y), reciprocal<true>(c4.z)};
+    pd.cyc = mode == 1;
+    bool take = active && ordinary && mode != 2;
+    if (!bvh_walk_coop<false>(b, rec, o, c1, pd, take, L, best_t, best_slot, dir_used)) take = false;   // list full: nobody has a result
+    if (__builtin_amdgcn_ballot_w64(active && !take) != 0ull) {   // the few lanes the pair walk cannot serve: alone, the literal way
+        if (active && !take) bvh_walk_general<FAST, false>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot, dir_used);
+    }
+}
+
+// Called by ALL lanes of the wavefront; `active`: this lane has a ray.  coop: the shared pair walk's LDS, or null.
 template <bool FAST, bool BVH>
-__device__ __forceinline__ HitInfo trace_any(const ShadeScene& sc, const BvhView& b, V3 o, V3 d, int force_mode, int* __restrict__ stack) {
-    // Hitable::hit at the world level: ScaleRay normalises (transform.h:50-54)
-    const V3 d1 = FAST ? unit_vector_fast(d) : unit_vector(d);
+__device__ __forceinline__ HitInfo trace_any(const ShadeScene& sc, const BvhView& b, V3 o, V3 d, int force_mode, int* __restrict__ stack,
+                                             bool active, const CoopLds* coop) {
     HitInfo h;
-    V3 used;
-    if (BVH) bvh_trace<FAST, false>(b, sc.base, o, d1, force_mode, h.t, h.idx, used, stack, 256);
-    else list_trace_any<FAST>(sc, o, d1, h.t, h.idx, used);
-    if (h.idx >= 0) {
+    h.t = FLT_MAX;
+    h.idx = -1;
+    V3 used = V3{0.0f, 0.0f, 0.0f};
+    if (BVH && coop != nullptr) {
+        // Hitable::hit at the world level: ScaleRay normalises (transform.h:50-54)
+        const V3 d1 = FAST ? unit_vector_fast(d) : unit_vector(d);
+        bvh_trace_coop<FAST>(b, sc.base, o, d1, force_mode, active, *coop, h.t, h.idx, used);
+    } else if (active) {
+        const V3 d1 = FAST ? unit_vector_fast(d) : unit_vector(d);
+        if (BVH) bvh_trace<FAST, false>(b, sc.base, o, d1, force_mode, h.t, h.idx, used, stack, 256);
+        else list_trace_any<FAST>(sc, o, d1, h.t, h.idx, used);
+    }
+    if (active && h.idx >= 0) {
         h.p = V3{o.x + h.t * used.x, o.y + h.t * used.y, o.z + h.t * used.z};   // rec.p = r.point_at_t(rec.t), triangle.h:95
         const float* n = sc.shade_n + (size_t)h.idx * 3;
         h.normal = V3{n[0], n[1], n[2]};
@@ -171,41 +385,117 @@ __global__ void __launch_bounds__(256, CRT_GENERIC_OCC)
 __global__ void __launch_bounds__(256)
 #endif
 render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __restrict__ state, float* __restrict__ rgb,
-                      int shader, int max_depth, int force_mode) {
-    __shared__ unsigned short level_mat[kMaxDepthLevels][256];   // material indices (crt_scene_set_materials: at most 65 536 materials)
-    extern __shared__ int pair_stack[];   // bvh_walk_pairs: kPairStackDepth x 256 pending right children (launched with it only when the pair records are used)
-    int* const stack = (BVH && b.pairs != nullptr) ? &pair_stack[threadIdx.x] : nullptr;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int xr = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int lyr = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool valid = xr < p.nx && lyr < p.row_count;                 // render.h:109
-    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
-    const int x = min(xr, p.nx - 1), ly = min(lyr, p.row_count - 1);    // lanes off the image replay a valid pixel (unstored)
-    const int y = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
-    const long long pixel_index = (long long)y * p.nx + x;
-    const long long si = (long long)ly * p.nx + x, stride = p.rng_count;
-    Xorwow rs;
-    rs.d = state[0 * stride + si]; rs.v0 = state[1 * stride + si]; rs.v1 = state[2 * stride + si];
-    rs.v2 = state[3 * stride + si]; rs.v3 = state[4 * stride + si]; rs.v4 = state[5 * stride + si];
+                      int shader, int max_depth, int force_mode, unsigned* __restrict__ pixel_queue, int walk_mode, int coop_cap) {
+    // dynamic LDS: [the pair walk's area: walk_mode 2: kCoopWaveBytes per wavefront (bvh_walk_coop); 1: kPairArea x 256 ints
+    // (bvh_walk_pairs, one stack per lane); 0: none] [material indices of shade's levels, max(1, max_depth) x 256
+    // (crt_scene_set_materials: at most 65 536 materials)]
+    extern __shared__ float4 dyn_lds[];
+    const int pair_bytes = !BVH ? 0 : (walk_mode == 2 ? 4 * kCoopWaveBytes : (walk_mode == 1 ? kPairArea * 256 * 4 : 0));
+    int* const stack = (BVH && walk_mode == 1) ? reinterpret_cast<int*>(dyn_lds) + threadIdx.x : nullptr;
+    unsigned short* const level_mat = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(dyn_lds) + pair_bytes) + threadIdx.x;
+    CoopLds coop_lds;
+    {
+        char* base = reinterpret_cast<char*>(dyn_lds) + (threadIdx.x >> 6) * kCoopWaveBytes;
+        coop_lds.rays = reinterpret_cast<float4*>(base);
+        coop_lds.best = reinterpret_cast<unsigned long long*>(base + 64 * kCoopRayVecs * 16);
+        coop_lds.nodes = reinterpret_cast<unsigned*>(base + 64 * kCoopRayVecs * 16 + 64 * 8);
+        coop_lds.tris = coop_lds.nodes + kCoopNodeCap;
+        coop_lds.cap = coop_cap;
+    }
+    const CoopLds* const coop = (BVH && walk_mode == 2) ? &coop_lds : nullptr;
+    const long long stride = p.rng_count;
     const V3 cam_o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
     const float fnx = (float)p.nx, fny = (float)p.ny;
+    // Persistent wavefronts, lane = one pixel AT A TIME: the pixels of the launch are a queue (8x8 tiles in row-major order,
+    // 64 queue positions per tile), a wavefront takes 64 positions with one atomic and hands them to its lanes as they
+    // become free.  A pixel's work is its own (its stream, its rays, its colour), whichever lane runs it, so pixels and
+    // states are the same bits as with one fixed pixel per lane — but a wavefront no longer lasts as long as its longest
+    // pixel (4 samples x 9 rays through glass against 4 rays of sky: the launch used to end with a few wavefronts of such
+    // pixels on an idle chip).  Every wavefront leaves when the queue is exhausted and its lanes are done.
+    const unsigned tiles_x = (unsigned)(p.nx + 7) >> 3, tiles_y = (unsigned)(p.row_count + 7) >> 3;
+    const unsigned total = tiles_x * tiles_y * 64u;                     // the host checks that this fits 32 bits
+    unsigned pool_next = 0, pool_end = 0;                               // wave-uniform: the positions this wavefront holds
+    bool exhausted = false;                                             // wave-uniform: the queue has nothing left
+#ifdef CRT_TUNING
+    b.walk_count = b.walk_stats && b.walk_stats[kStatsTimeline] == 0ull;
+    __shared__ unsigned tl_steps[4];
+    if ((threadIdx.x & 63) == 0) tl_steps[threadIdx.x >> 6] = 0u;
+    b.wave_steps = b.walk_stats ? &tl_steps[threadIdx.x >> 6] : nullptr;
+    unsigned tl_trips = 0, tl_pixels = 0;
+    const unsigned long long tl0 = b.walk_stats ? (unsigned long long)wall_clock64() : 0ull;   // 100 MHz
+    unsigned long long tl1 = 0ull;
+#endif
+    int x = 0, ly = 0, y = 0;
+    long long si = 0;
+    bool have = false;                                                  // this lane holds a pixel
+    Xorwow rs;
+    rs.d = rs.v0 = rs.v1 = rs.v2 = rs.v3 = rs.v4 = 0u;
     float colx = 0.0f, coly = 0.0f, colz = 0.0f;
     // One loop over RAYS, not over samples: every trip, each lane that has a path in flight traces its next ray —
     // the primary ray of its next sample or the next bounce of `shade` — so a lane whose path ended does not wait for
-    // the longest path of the wavefront before it starts its next sample (the wavefront's time is the longest SUM of
-    // a pixel's path lengths instead of the sum over samples of the longest path; the launch used to wait for its
-    // longest chains of bounces: DESIGN.md §4.8).  A pixel's own order of operations — u, v, lens draws, then per
-    // bounce the scatter draws — is unchanged, and its stream is its own, so pixels and states are the same bits.
-    // The wave votes inside the traversals are taken over the lanes that trace in that trip.
+    // the longest path of the wavefront before it starts its next sample.  A pixel's own order of operations — u, v,
+    // lens draws, then per bounce the scatter draws — is unchanged.  The wave votes inside the traversals are taken
+    // over the lanes that trace in that trip.
     int smp = 0, depth = 0, levels = 0;
     bool in_flight = false;
     V3 r_o = cam_o, r_d = V3{0.0f, 0.0f, 0.0f};
     for (;;) {
-        if (!in_flight && smp < p.samples) {                            // render.h:115-118: the next sample of this pixel
+        if (have && !in_flight && smp >= p.samples) {
+            // col /= float(ns); sqrt; clip (render.h:123-128, vec3.h:182-189,119-131)
+            const float k = (float)(1.0 / (double)(float)p.samples);
+            colx *= k; coly *= k; colz *= k;
+            colx = sqrtf(colx); coly = sqrtf(coly); colz = sqrtf(colz);
+            colx = (colx > 1.0f) ? 1.0f : ((colx < 0.0f) ? 0.0f : colx);
+            coly = (coly > 1.0f) ? 1.0f : ((coly < 0.0f) ? 0.0f : coly);
+            colz = (colz > 1.0f) ? 1.0f : ((colz < 0.0f) ? 0.0f : colz);
+            const size_t o = (size_t)si * 3;
+            rgb[o + 0] = colx; rgb[o + 1] = coly; rgb[o + 2] = colz;
+            state[0 * stride + si] = rs.d; state[1 * stride + si] = rs.v0; state[2 * stride + si] = rs.v1;
+            state[3 * stride + si] = rs.v2; state[4 * stride + si] = rs.v3; state[5 * stride + si] = rs.v4;
+            have = false;
+        }
+        for (;;) {                                                      // free lanes take the next pixels of the queue
+            const unsigned long long want = __builtin_amdgcn_ballot_w64(!have);
+            if (want == 0ull || exhausted) break;
+            if (pool_next == pool_end) {
+                unsigned base = 0;
+                if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) base = atomicAdd(pixel_queue, 64u);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= total) {
+                    exhausted = true;
+#ifdef CRT_TUNING
+                    if (b.walk_stats) tl1 = (unsigned long long)wall_clock64();
+#endif
+                    continue;
+                }
+                pool_next = base;
+                pool_end = base + 64u;                                  // total is a multiple of 64
+            }
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+            const unsigned q = pool_next + rank;
+            if (!have && q < pool_end) {
+                const unsigned tile = q >> 6, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+                x = (int)(txi * 8u + (q & 7u));
+                ly = (int)(tyi * 8u + ((q >> 3) & 7u));
+                if (x < p.nx && ly < p.row_count) {                     // render.h:109; positions off the image are dropped
+                    y = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
+                    si = (long long)ly * p.nx + x;
+                    rs.d = state[0 * stride + si]; rs.v0 = state[1 * stride + si]; rs.v1 = state[2 * stride + si];
+                    rs.v2 = state[3 * stride + si]; rs.v3 = state[4 * stride + si]; rs.v4 = state[5 * stride + si];
+                    colx = coly = colz = 0.0f;
+                    smp = 0;
+                    have = true;
+#ifdef CRT_TUNING
+                    tl_pixels += 1u;   // per lane; summed below
+#endif
+                }
+            }
+            pool_next = min(pool_next + (unsigned)__builtin_popcountll(want), pool_end);
+        }
+        if (have && !in_flight && smp < p.samples) {                    // render.h:115-118: the next sample of this pixel
             const float u = ((float)x + xw_uniform(rs)) / fnx;          // render.h:116
             const float v = ((float)y + xw_uniform(rs)) / fny;          // render.h:117
-            if (pixel_index == 0) {                                     // get_ray's lens sample from state[0] (render.h:118): DESIGN.md §1
+            if (y == 0 && x == 0) {                                     // get_ray's lens sample from state[0] (render.h:118): DESIGN.md §1
                 float px, py;
                 do {
                     px = xw_uniform_2m1(rs);
@@ -219,9 +509,31 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
             in_flight = true;
             ++smp;
         }
-        if (__builtin_amdgcn_ballot_w64(in_flight) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(in_flight) == 0ull) {
+            if (exhausted && __builtin_amdgcn_ballot_w64(have) == 0ull) {
+#ifdef CRT_TUNING
+                if (b.walk_stats && (threadIdx.x & 63) == 0) {   // [8] latest "queue empty" [9] latest end [10] ~earliest start [11..13] sums: start..empty, start..end, waves
+                    const unsigned long long tl2 = (unsigned long long)wall_clock64();
+                    atomicMax(&b.walk_stats[8], tl1); atomicMax(&b.walk_stats[9], tl2); atomicMax(&b.walk_stats[10], ~tl0);
+                    atomicAdd(&b.walk_stats[11], tl1 - tl0); atomicAdd(&b.walk_stats[12], tl2 - tl0); atomicAdd(&b.walk_stats[13], 1ull);
+                    const unsigned slot = blockIdx.x * 4u + (threadIdx.x >> 6);
+                    if (slot < (unsigned)kStatsWaveSlots) {   // per wavefront: start, queue empty, end, steps << 40 | trips << 20 | pixels
+                        unsigned long long* w = b.walk_stats + kStatsWaveLog + 4 * (size_t)slot;
+                        w[0] = tl0; w[1] = tl1; w[2] = tl2;
+                        w[3] = ((unsigned long long)tl_steps[threadIdx.x >> 6] << 40) | ((unsigned long long)tl_trips << 20) | tl_pixels;
+                    }
+                }
+#endif
+                break;
+            }
+            continue;                                                   // pixels to store (samples == 0) or positions off the image
+        }
+        walk_stat(b, 0, __builtin_amdgcn_ballot_w64(in_flight));
+#ifdef CRT_TUNING
+        ++tl_trips;
+#endif
+        const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode, stack, in_flight, coop);   // all lanes: the shared walk needs them
         if (in_flight) {
-            const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode, stack);
             V3 L = V3{0.0f, 0.0f, 0.0f};
             bool done = true;
             if (shader == 1) {
@@ -235,7 +547,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
                     const MaterialPOD m = sc.materials[mi];
                     V3 att, s_o, s_d;
                     if (depth > 0 && scatter_dev(m, r_d, rec, att, s_o, s_d, rs)) {   // render.h:58
-                        level_mat[levels][threadIdx.x] = (unsigned short)mi;
+                        level_mat[levels * 256] = (unsigned short)mi;
                         ++levels;
                         --depth;
                         r_o = s_o;
@@ -250,7 +562,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
                     // Coming back up: emitted + attenuation * (deeper result), render.h:59; a material that
                     // scattered is not a light, so emitted = vec3(0,0,0) (material.h:49-53).
                     for (int k = levels - 1; k >= 0; --k) {
-                        const MaterialPOD m = sc.materials[level_mat[k][threadIdx.x]];
+                        const MaterialPOD m = sc.materials[level_mat[k * 256]];
                         const V3 att = (m.kind == 2) ? V3{1.0f, 1.0f, 1.0f} : V3{m.albedo[0], m.albedo[1], m.albedo[2]};
                         L = V3{0.0f + att.x * L.x, 0.0f + att.y * L.y, 0.0f + att.z * L.z};
                     }
@@ -278,24 +590,13 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
             }
         }
     }
-    // col /= float(ns); sqrt; clip (render.h:123-128, vec3.h:182-189,119-131)
-    const float k = (float)(1.0 / (double)(float)p.samples);
-    colx *= k; coly *= k; colz *= k;
-    colx = sqrtf(colx); coly = sqrtf(coly); colz = sqrtf(colz);
-    colx = (colx > 1.0f) ? 1.0f : ((colx < 0.0f) ? 0.0f : colx);
-    coly = (coly > 1.0f) ? 1.0f : ((coly < 0.0f) ? 0.0f : coly);
-    colz = (colz > 1.0f) ? 1.0f : ((colz < 0.0f) ? 0.0f : colz);
-    if (!valid) return;
-    const size_t o = ((size_t)ly * p.nx + x) * 3;
-    rgb[o + 0] = colx; rgb[o + 1] = coly; rgb[o + 2] = colz;
-    state[0 * stride + si] = rs.d; state[1 * stride + si] = rs.v0; state[2 * stride + si] = rs.v1;
-    state[3 * stride + si] = rs.v2; state[4 * stride + si] = rs.v3; state[5 * stride + si] = rs.v4;
 }
 
 hipError_t launch_render_generic(const RenderParams& p, const float* d_base, const float* d_shade_n, const int* d_material_of,
                                  const void* d_materials, int n_tris, const float4* d_nodes, int n_nodes, const float rot[9],
                                  uint32_t* d_state, float* d_rgb, bool bvh, bool fast, int shader, int max_depth, int force_mode,
-                                 hipStream_t stream, const float4* d_pairs, const int* d_partner) {
+                                 hipStream_t stream, const float4* d_pairs, const int* d_partner, int walk_mode, unsigned* d_pixel_queue, int n_cus,
+                                 unsigned long long* d_stats) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     ShadeScene sc;
     sc.base = d_base; sc.shade_n = d_shade_n; sc.material_of = d_material_of;
@@ -303,12 +604,34 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
     sc.n_tris = n_tris;
     BvhView b;
     b.nodes = d_nodes; b.n_nodes = n_nodes;
-    b.pairs = d_pairs; b.partner = d_partner;
+    if (!bvh || d_pairs == nullptr) walk_mode = 0;
+    int coop_cap = kCoopNodeCap;
+    if (walk_mode == 3) {   // test hook: the shared walk with a list so short that trips are abandoned
+        walk_mode = 2;
+        coop_cap = 96;
+    }
+    b.pairs = walk_mode ? d_pairs : nullptr; b.partner = d_partner;
+#ifdef CRT_TUNING
+    b.walk_stats = d_stats;
+#endif
     for (int k = 0; k < 9; ++k) { sc.rot[k] = rot[k]; b.rot[k] = rot[k]; }
-    dim3 block(256), grid((unsigned)((p.nx + 15) / 16), (unsigned)((p.row_count + 15) / 16));
     auto fn = bvh ? (fast ? render_generic_kernel<true, true> : render_generic_kernel<false, true>)
                   : (fast ? render_generic_kernel<true, false> : render_generic_kernel<false, false>);
-    const size_t lds = (bvh && d_pairs != nullptr) ? (size_t)kPairStackDepth * 256 * sizeof(int) : 0;
-    hipLaunchKernelGGL(fn, grid, block, lds, stream, p, sc, b, d_state, d_rgb, shader, max_depth, force_mode);
+    const size_t lds = (walk_mode == 2 ? (size_t)4 * kCoopWaveBytes : (walk_mode == 1 ? (size_t)kPairArea * 256 * sizeof(int) : 0)) +
+                       (size_t)std::min(std::max(1, max_depth), kMaxDepthLevels) * 256 * sizeof(unsigned short);
+    // persistent blocks: as many as are resident at once, fewer for small frames
+    const unsigned long long tiles = (unsigned long long)((p.nx + 7) / 8) * (unsigned long long)((p.row_count + 7) / 8);
+    if (tiles * 64ull >= 0xffff0000ull) return hipErrorInvalidValue;   // the queue cursor is 32 bits (a 65 000 x 65 000 frame)
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds);
+    if (e != hipSuccess) return e;
+    unsigned resident = (unsigned)std::max(1, n_cus) * (unsigned)std::max(1, per_cu);
+#ifdef CRT_TUNING
+    if (const char* ev = getenv("CRT_GENERIC_BLOCKS")) resident = (unsigned)std::max(1, atoi(ev));   // resident blocks in total
+#endif
+    dim3 block(256), grid((unsigned)std::min<unsigned long long>((tiles + 3) / 4, resident));
+    e = hipMemsetAsync(d_pixel_queue, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, grid, block, lds, stream, p, sc, b, d_state, d_rgb, shader, max_depth, force_mode, d_pixel_queue, walk_mode, coop_cap);
     return hipGetLastError();
 }

@@ -146,7 +146,7 @@ def test_gpu_shaders_and_materials_match_oracle(gpu, oracle, kind, world):
         # with tiny capacities = shared tiles and the pool fallback, 3, and with a full binning log, 8) and the generic kernel (1)
         variants = (0,)
         if world == "bvh" and shader == api.SHADER_SHADE and depth == 8:
-            variants = (0, 5, 6, 9)
+            variants = (0, 5, 6, 9, 11, 12)   # 9 skip links, 11 one stack per lane, 12 the shared walk with a short list (abandoned trips)
         elif shader in (api.SHADER_LAMBERT, api.SHADER_NORMAL):
             variants = (0, 1, 3, 8) if world == "list" else (0, 1)
         for variant in variants:
@@ -244,6 +244,12 @@ def test_gpu_shade_on_the_c3_mesh_matches_oracle_crops(gpu, oracle, tmp_path):
     api.create_BVHfromList(scene, st)
     scene.set_materials(mats, of)
     got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH, api.SHADER_SHADE, 8)
+    after = st.export()
+    for variant in (9, 11, 12):   # the whole frame, every walk: skip links, one stack per lane, the shared walk with abandoned trips
+        st2 = api.SetCurandState(nx, ny, 0)   # state[0] (pixel 0's stream) differs: the BVH build drew from st's
+        got2 = hip_render(gpu, scene, cam, st2, nx, ny, spp, api.WORLD_BVH, api.SHADER_SHADE, 8, variant)
+        assert same(got2.reshape(-1, 3)[1:], got.reshape(-1, 3)[1:]), variant
+        assert np.array_equal(st2.export()[1:], after[1:]), variant
     lam = (got[..., 0] - got[..., 2]) > 0.05                                   # something that is not sky
     rows_hit = np.where(lam.any(axis=1))[0]
     r_mid = int((rows_hit[0] + rows_hit[-1]) // 2)
