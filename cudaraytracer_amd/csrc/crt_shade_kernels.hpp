@@ -71,7 +71,7 @@ __device__ __forceinline__ void list_trace_any(const ShadeScene& sc, V3 o, V3 d1
 // results meet in one 64-bit key per ray under atomicMin — smallest t, among equal t the larger partner (bvh_walk_pairs'
 // merge rule, a total order).
 constexpr int kCoopNodeCap = 1024;   // node items per wavefront (newest first: at most 64 per level of the tree pending — more: the trip is redone by the literal walk)
-constexpr int kCoopTriCap = 320;     // triangle items: fewer than 64 before a round of nodes, at most 4 more per lane
+constexpr int kCoopTriCap = 576;     // triangle items: fewer than 64 before a round of nodes, at most 8 more per lane
 constexpr int kCoopRayVecs = 5;      // float4 per ray: (o, cyc) c3 y3 c4 y4
 constexpr int kCoopWaveBytes = 64 * kCoopRayVecs * 16 + 64 * 8 + kCoopNodeCap * 4 + kCoopTriCap * 4;
 struct CoopLds {
@@ -86,21 +86,48 @@ struct PairStep {                // what one pair record yields for one ray
     int ref_l = 0, ref_r = 0;
     int cnt_l = 0, cnt_r = 0;          // triangles of hit leaf children (0: not a leaf, or missed)
 };
-__device__ __forceinline__ PairStep pair_step(const BvhView& b, int cur, V3 o, V3 d, V3 y, V3 dt) {
+struct PairRec {
+    float4 p0, p1, p2, p3;
+};
+__device__ __forceinline__ PairRec pair_load(const BvhView& b, unsigned cur) {
     const float4* __restrict__ pr = b.pairs + 4 * (size_t)cur;
-    const float4 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
-    const bool hit_l = box_hit_fast(p0, make_float4(p1.x, p1.y, 0.0f, 0.0f), o, d, y);
-    const bool hit_r = box_hit_fast(make_float4(p1.z, p1.w, p2.x, p2.y), make_float4(p2.z, p2.w, 0.0f, 0.0f), o, d, y);
+    return PairRec{pr[0], pr[1], pr[2], pr[3]};
+}
+// `has`: the lane holds an item (otherwise the result is empty, whatever the operands)
+__device__ __forceinline__ PairStep pair_eval(const PairRec& r, bool has, V3 o, V3 d, V3 y, V3 dt) {
+    const bool hit_l = has && box_hit_fast(r.p0, make_float4(r.p1.x, r.p1.y, 0.0f, 0.0f), o, d, y);
+    const bool hit_r = has && box_hit_fast(make_float4(r.p1.z, r.p1.w, r.p2.x, r.p2.y), make_float4(r.p2.z, r.p2.w, 0.0f, 0.0f), o, d, y);
     PairStep s;
-    s.ref_l = __float_as_int(p3.x);
-    s.ref_r = __float_as_int(p3.y);
+    s.ref_l = __float_as_int(r.p3.x);
+    s.ref_r = __float_as_int(r.p3.y);
     // normal cones as in bvh_walk_pairs: a child none of whose triangles can pass triangle.h:61 is skipped like a missed box
-    const bool try_l = hit_l && !cone_rejects(__float_as_uint(p3.z), dt), try_r = hit_r && !cone_rejects(__float_as_uint(p3.w), dt);
+    const bool try_l = hit_l && !cone_rejects(__float_as_uint(r.p3.z), dt), try_r = hit_r && !cone_rejects(__float_as_uint(r.p3.w), dt);
     s.go_l = try_l && s.ref_l >= 0;
     s.go_r = try_r && s.ref_r >= 0;
     s.cnt_l = (try_l && s.ref_l < 0) ? ((s.ref_l >> 24) & 3) : 0;
     s.cnt_r = (try_r && s.ref_r < 0) ? ((s.ref_r >> 24) & 3) : 0;
     return s;
+}
+// one node item of the shared walk: its ray's data from LDS (class -> which chain elements its boxes and triangles see)
+struct CoopItem {
+    unsigned ray, child_class;
+    bool tri3;
+    V3 o, d, y, dt;
+};
+__device__ __forceinline__ CoopItem coop_item(const CoopLds& L, unsigned item) {
+    CoopItem c;
+    c.ray = item >> 26;
+    const unsigned cls = (item >> 24) & 3u;   // 1: depth 1 (k = 3)   2: even depth >= 2   3: odd depth >= 3
+    const float4 ro = L.rays[c.ray * kCoopRayVecs];
+    const bool cyc = ro.w != 0.0f;
+    const bool odd = cls != 2u;                    // k = depth + 2 is odd
+    const bool box3 = cls == 1u || (cyc && odd);   // pair_uses_c3
+    c.tri3 = cyc && odd;                           // the triangles of a leaf child see k + 2
+    const float4 rd = L.rays[c.ray * kCoopRayVecs + (box3 ? 1 : 3)], ry = L.rays[c.ray * kCoopRayVecs + (box3 ? 2 : 4)];
+    const float4 rt = L.rays[c.ray * kCoopRayVecs + (c.tri3 ? 1 : 3)];
+    c.o = V3{ro.x, ro.y, ro.z}; c.d = V3{rd.x, rd.y, rd.z}; c.y = V3{ry.x, ry.y, ry.z}; c.dt = V3{rt.x, rt.y, rt.z};
+    c.child_class = cls == 2u ? 3u : 2u;
+    return c;
 }
 __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -152,8 +179,7 @@ __device__ __forceinline__ bool bvh_walk_coop(const BvhView& b, const float* __r
     L.best[lane] = ~0ull;
     unsigned nn = 0, nt = 0;   // wave-uniform list lengths
     {   // the root's record by the rays' own lanes, from registers: its children's boxes see c2 (k = 2), triangles of a leaf child k = 4
-        PairStep s;
-        if (alive) s = pair_step(b, 0, o, pd.c2, pd.y2, pd.c4);
+        const PairStep s = pair_eval(pair_load(b, 0u), alive, o, pd.c2, pd.y2, pd.c4);
         coop_push(L, lane, 1u, false, s, nn, nt);
     }
     coop_sync();
@@ -175,32 +201,25 @@ __device__ __forceinline__ bool bvh_walk_coop(const BvhView& b, const float* __r
                     atomicMin(&L.best[ray], hit_key(t, (int)(((0xffffffu - partner) << 3) | (place << 1) | (tri3 ? 1u : 0u))));
                 }
             }
-        } else {                        // a round of pair records
-            const unsigned n = min(nn, 64u);
+        } else {                        // a round of pair records: the 128 newest, two per lane (both records in flight together)
+            const unsigned n = min(nn, 128u);
             if (nn + n > (unsigned)L.cap) {
+                walk_stat(b, 6, 0ull);   // [6] abandoned trips
                 ok = false;
                 break;
             }
             nn -= n;
-            walk_stat(b, 2, __builtin_amdgcn_ballot_w64(lane < n));
-            PairStep s;
-            unsigned ray = 0u, child_class = 2u;
-            bool tri3 = false;
-            if (lane < n) {
-                const unsigned item = L.nodes[nn + lane];
-                ray = item >> 26;
-                const unsigned cls = (item >> 24) & 3u;   // 1: depth 1 (k = 3)   2: even depth >= 2   3: odd depth >= 3
-                const float4 ro = L.rays[ray * kCoopRayVecs];
-                const bool cyc = ro.w != 0.0f;
-                const bool odd = cls != 2u;                // k = depth + 2 is odd
-                const bool box3 = cls == 1u || (cyc && odd);   // pair_uses_c3
-                tri3 = cyc && odd;                             // the triangles of a leaf child see k + 2
-                const float4 rd = L.rays[ray * kCoopRayVecs + (box3 ? 1 : 3)], ry = L.rays[ray * kCoopRayVecs + (box3 ? 2 : 4)];
-                const float4 rt = L.rays[ray * kCoopRayVecs + (tri3 ? 1 : 3)];
-                s = pair_step(b, (int)(item & 0xffffffu), V3{ro.x, ro.y, ro.z}, V3{rd.x, rd.y, rd.z}, V3{ry.x, ry.y, ry.z}, V3{rt.x, rt.y, rt.z});
-                child_class = cls == 2u ? 3u : 2u;
-            }
-            coop_push(L, ray, child_class, tri3, s, nn, nt);
+            const bool has_a = lane < n, has_b = lane + 64u < n;
+            walk_stat(b, 2, __builtin_amdgcn_ballot_w64(has_a));
+            if (n > 64u) walk_stat(b, 2, __builtin_amdgcn_ballot_w64(has_b));
+            // a lane without an item reads item 0's place and the root's record (hot), and its result is masked
+            const unsigned item_a = L.nodes[has_a ? nn + lane : 0u], item_b = L.nodes[has_b ? nn + 64u + lane : 0u];
+            const PairRec rec_a = pair_load(b, has_a ? (item_a & 0xffffffu) : 0u), rec_b = pair_load(b, has_b ? (item_b & 0xffffffu) : 0u);
+            const CoopItem ca = coop_item(L, has_a ? item_a : 0u), cb = coop_item(L, has_b ? item_b : 0u);
+            const PairStep sa = pair_eval(rec_a, has_a, ca.o, ca.d, ca.y, ca.dt);
+            const PairStep sb = pair_eval(rec_b, has_b, cb.o, cb.d, cb.y, cb.dt);
+            coop_push(L, ca.ray, ca.child_class, ca.tri3, sa, nn, nt);
+            if (n > 64u) coop_push(L, cb.ray, cb.child_class, cb.tri3, sb, nn, nt);
         }
         coop_sync();
     }
@@ -377,7 +396,7 @@ __device__ __forceinline__ V3 sky_of(V3 d) {   // backgroundSky(d), render.h:41-
 // shader: 0 LambertShade, 1 shade, 2 shade_normal.  256 threads = four 8x8 pixel tiles.
 template <bool FAST, bool BVH>
 #ifndef CRT_GENERIC_OCC
-#define CRT_GENERIC_OCC 4   // waves per SIMD the register allocation aims at (the pair walk sits at 129 VGPRs without a target: 3 waves)
+#define CRT_GENERIC_OCC 3   // waves per SIMD the register allocation aims at: the shared walk's LDS admits three blocks per CU
 #endif
 #if CRT_GENERIC_OCC
 __global__ void __launch_bounds__(256, CRT_GENERIC_OCC)
@@ -385,7 +404,8 @@ __global__ void __launch_bounds__(256, CRT_GENERIC_OCC)
 __global__ void __launch_bounds__(256)
 #endif
 render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __restrict__ state, float* __restrict__ rgb,
-                      int shader, int max_depth, int force_mode, unsigned* __restrict__ pixel_queue, int walk_mode, int coop_cap) {
+                      int shader, int max_depth, int force_mode, unsigned* __restrict__ pixel_queue, int walk_mode, int coop_cap,
+                      unsigned chunk_log, unsigned perm_mul) {
     // dynamic LDS: [the pair walk's area: walk_mode 2: kCoopWaveBytes per wavefront (bvh_walk_coop); 1: kPairArea x 256 ints
     // (bvh_walk_pairs, one stack per lane); 0: none] [material indices of shade's levels, max(1, max_depth) x 256
     // (crt_scene_set_materials: at most 65 536 materials)]
@@ -474,9 +494,15 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
             const unsigned q = pool_next + rank;
             if (!have && q < pool_end) {
-                const unsigned tile = q >> 6, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-                x = (int)(txi * 8u + (q & 7u));
-                ly = (int)(tyi * 8u + ((q >> 3) & 7u));
+                // the queue is dealt out in chunks of 1 << chunk_log positions (whole rows of a tile) in a scattered order (chunk * mul mod
+                // n_chunks, mul coprime to n_chunks: host): the pixels a wavefront holds come from all over the frame, so the long
+                // pixels of one region (glass: 36 rays in sequence) are spread over all wavefronts instead of filling a few
+                const unsigned chunk = ((q >> chunk_log) * perm_mul) % (total >> chunk_log), within = q & ((1u << chunk_log) - 1u);
+                const unsigned tile = chunk >> (6 - chunk_log), sub = chunk & ((1u << (6 - chunk_log)) - 1u);
+                const unsigned tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+                const unsigned in_tile = (sub << chunk_log) + within;   // 0..63, row-major in the 8x8 tile
+                x = (int)(txi * 8u + (in_tile & 7u));
+                ly = (int)(tyi * 8u + (in_tile >> 3));
                 if (x < p.nx && ly < p.row_count) {                     // render.h:109; positions off the image are dropped
                     y = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
                     si = (long long)ly * p.nx + x;
@@ -632,6 +658,24 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
     dim3 block(256), grid((unsigned)std::min<unsigned long long>((tiles + 3) / 4, resident));
     e = hipMemsetAsync(d_pixel_queue, 0, sizeof(unsigned), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, grid, block, lds, stream, p, sc, b, d_state, d_rgb, shader, max_depth, force_mode, d_pixel_queue, walk_mode, coop_cap);
+    // the order of the pixel queue: chunks of 4 positions, chunk c at place c * mul mod n_chunks (tools/sweep_queue.sh)
+    unsigned chunk_log = 2, perm_mul = 1;
+#ifdef CRT_TUNING
+    if (const char* ev = getenv("CRT_QUEUE_CHUNK_LOG")) chunk_log = (unsigned)std::min(6, std::max(0, atoi(ev)));
+#endif
+    {
+        const unsigned long long n_chunks = tiles * 64ull >> chunk_log;
+        static const unsigned primes[] = {1999u, 1997u, 1993u, 1987u, 1979u, 1973u, 1951u, 1949u};   // the first that does not divide n_chunks
+        for (unsigned pr : primes)
+            if (n_chunks % pr != 0ull && n_chunks * pr < 0xffffffffull) {
+                perm_mul = pr;
+                break;
+            }
+#ifdef CRT_TUNING
+        if (const char* ev = getenv("CRT_QUEUE_SCATTER")) if (atoi(ev) == 0) perm_mul = 1;
+#endif
+    }
+    hipLaunchKernelGGL(fn, grid, block, lds, stream, p, sc, b, d_state, d_rgb, shader, max_depth, force_mode, d_pixel_queue, walk_mode, coop_cap,
+                       chunk_log, perm_mul);
     return hipGetLastError();
 }

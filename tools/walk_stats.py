@@ -21,6 +21,7 @@ torch.cuda.synchronize()
 s = api.tiled_stats(0)
 for name, k in (("trips (lanes in flight)", 0), ("walk steps (lanes walking)", 2), ("triangle rounds (lanes testing)", 4)):
     print("%-34s %12d   lanes %.1f of 64" % (name, s[k], s[k + 1] / max(1, s[k])))
+print("abandoned trips: %d" % s[6])
 print("rays: %d (%.2f per primary ray); walk steps per ray %.1f, triangle tests per ray %.1f" % (s[1], s[1] / (nx * ny * spp), s[3] / max(1, s[1]), s[5] / max(1, s[1])))
 api.tiled_stats(2)   # time stamps only, at full speed
 api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=8, stream=torch.cuda.current_stream())
@@ -31,6 +32,7 @@ t0 = (~s[10]) & 0xffffffffffffffff
 w = max(1, s[13])
 print("waves %d: queue empty for the last wave after %.2f ms, last wave ends after %.2f ms; mean over waves: queue empty after %.2f ms, end after %.2f ms"
       % (s[13], (s[8] - t0) / 1e5, (s[9] - t0) / 1e5, s[11] / w / 1e5, s[12] / w / 1e5))
+tl = tl[tl[:, 2] != 0]
 t0w = tl[:, 0].min()
 end = (tl[:, 2] - t0w) / 1e5
 empty = (tl[:, 1] - t0w) / 1e5
@@ -42,4 +44,4 @@ print("per wavefront, by end time: percentile  end ms  queue-empty ms  walk step
 for q in (0, 10, 25, 50, 75, 90, 95, 98, 99, 99.5, 99.9, 100):
     i = order[min(len(order) - 1, int(q / 100 * len(order)))]
     print("  %5.1f %8.2f %8.2f %8d %6d %5d" % (q, end[i], empty[i], steps[i], trips[i], pix0[i]))
-print("sum of steps %d; waves ending after 5 ms: %d, after 10 ms: %d" % (steps.sum(), (end > 5).sum(), (end > 10).sum()))
+print("%d wavefronts; sum of steps %d; ending after 5 ms: %d, after 8 ms: %d, after 10 ms: %d" % (len(tl), steps.sum(), (end > 5).sum(), (end > 8).sum(), (end > 10).sum()))
