@@ -944,7 +944,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         float rot[9];
         rotation_zero_matrix(rot);
         const crt_bvh* t = world == 1 ? scene->bvh : nullptr;
-        if (!cx.d_pixel_queue) HIP_TRY(hipMalloc(&cx.d_pixel_queue, 64));
+        if (!cx.d_pixel_queue) HIP_TRY(hipMalloc(&cx.d_pixel_queue, crt::kGenericQueueWords * sizeof(unsigned)));
         if (!cx.n_cus) HIP_TRY(hipDeviceGetAttribute(&cx.n_cus, hipDeviceAttributeMultiprocessorCount, cx.device));
         HIP_TRY(crt::launch_render_generic(p, t ? t->d_base_slots : scene->d_base, t ? t->d_shade_n_slots : scene->d_shade_n,
                                            t ? t->d_material_slots : scene->d_material_of, scene->d_materials, scene->n_tris,

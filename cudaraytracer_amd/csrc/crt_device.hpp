@@ -176,6 +176,8 @@ hipError_t launch_render_bvh(const RenderParams& p, const float4* d_nodes, int n
 // pair records of the tree (crt_bvh_kernels.hpp: bvh_walk_pairs): boxes refreshed from the flat nodes
 hipError_t launch_bvh_pairs(const float4* d_nodes, float4* d_pairs, const int* d_pair_flat, int n_pairs, hipStream_t stream);
 constexpr float kConeScale = 1.02f / 254.0f;   // threshold byte of a pair record's normal cone -> threshold (crt_bvh.cpp: cone_of)
+constexpr int kGenericQueueWords = 16;   // render_generic_kernel's queue cursor (launch context)
+constexpr int kGenericChunkLog = 2;      // its pixel queue is dealt out in chunks of 4 positions
 constexpr int kPairArea = 32;        // ints of LDS per lane for bvh_walk_pairs: the stack from the bottom, queued triangles from the top
 constexpr int kPairStackDepth = 24;   // entries of the per-lane stack of bvh_walk_pairs (one per tree level); deeper trees keep the skip-link walk
 // The generic render kernel (crt_shade_kernels.hpp): shader 0 LambertShade, 1 shade (recursive, depth
@@ -189,7 +191,7 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
                                  hipStream_t stream, const float4* d_pairs, const int* d_partner, int walk_mode, unsigned* d_pixel_queue, int n_cus,
                                  unsigned long long* d_stats = nullptr);   // d_stats: tuning builds only (BvhView::walk_stats)
 // walk_mode (BVH world with pair records): 2 the wavefront shares the walk (bvh_walk_coop), 1 one stack per lane (bvh_walk_pairs),
-// 0 skip links, 3 the shared walk with a short list (test hook).  d_pixel_queue: one word of device memory owned by the launch context (the cursor of the kernel's pixel queue; zeroed on `stream` first)
+// 0 skip links, 3 the shared walk with a short list (test hook).  d_pixel_queue: kGenericQueueWords words of the launch context.
 // What the tiled kernels need of the tree to serve the BVH world's PRIMARY rays:
 // a triangle is hit through the tree iff it passes Triangle::collision_detection AND the boxes of its
 // leaf and of all the leaf's ancestors pass AABB::hit — the tile lists (a superset of the first

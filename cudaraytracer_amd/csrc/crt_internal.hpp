@@ -53,7 +53,7 @@ struct Context {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
     bool ev_has_mid = false, ev_valid = false;
     crt::LaunchCache cache, cache_bvh;
-    unsigned* d_pixel_queue = nullptr;   // render_generic_kernel's queue cursor
+    unsigned* d_pixel_queue = nullptr;   // render_generic_kernel's queue cursor (kGenericQueueWords)
 };
 
 Context* context_for(int device, hipStream_t stream);

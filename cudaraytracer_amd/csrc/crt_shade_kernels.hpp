@@ -282,18 +282,20 @@ __device__ __forceinline__ void bvh_trace_coop(const BvhView& b, const float* __
     }
 }
 
-// Called by ALL lanes of the wavefront; `active`: this lane has a ray.  coop: the shared pair walk's LDS, or null.
+// Called by ALL lanes of the wavefront; `active`: this lane has a ray.  use_coop: the shared pair walk (its LDS: coop).
+// (coop by reference and not behind a pointer that may be null: the struct then stays in registers and its members keep
+// their LDS address space — through a pointer the walk's LDS traffic became FLAT instructions.)
 template <bool FAST, bool BVH>
 __device__ __forceinline__ HitInfo trace_any(const ShadeScene& sc, const BvhView& b, V3 o, V3 d, int force_mode, int* __restrict__ stack,
-                                             bool active, const CoopLds* coop) {
+                                             bool active, bool use_coop, const CoopLds& coop) {
     HitInfo h;
     h.t = FLT_MAX;
     h.idx = -1;
     V3 used = V3{0.0f, 0.0f, 0.0f};
-    if (BVH && coop != nullptr) {
+    if (BVH && use_coop) {
         // Hitable::hit at the world level: ScaleRay normalises (transform.h:50-54)
         const V3 d1 = FAST ? unit_vector_fast(d) : unit_vector(d);
-        bvh_trace_coop<FAST>(b, sc.base, o, d1, force_mode, active, *coop, h.t, h.idx, used);
+        bvh_trace_coop<FAST>(b, sc.base, o, d1, force_mode, active, coop, h.t, h.idx, used);
     } else if (active) {
         const V3 d1 = FAST ? unit_vector_fast(d) : unit_vector(d);
         if (BVH) bvh_trace<FAST, false>(b, sc.base, o, d1, force_mode, h.t, h.idx, used, stack, 256);
@@ -422,13 +424,13 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
         coop_lds.tris = coop_lds.nodes + kCoopNodeCap;
         coop_lds.cap = coop_cap;
     }
-    const CoopLds* const coop = (BVH && walk_mode == 2) ? &coop_lds : nullptr;
+    const bool use_coop = BVH && walk_mode == 2;
     const long long stride = p.rng_count;
     const V3 cam_o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
     const float fnx = (float)p.nx, fny = (float)p.ny;
-    // Persistent wavefronts, lane = one pixel AT A TIME: the pixels of the launch are a queue (8x8 tiles in row-major order,
-    // 64 queue positions per tile), a wavefront takes 64 positions with one atomic and hands them to its lanes as they
-    // become free.  A pixel's work is its own (its stream, its rays, its colour), whichever lane runs it, so pixels and
+    // Persistent wavefronts, lane = one pixel AT A TIME: the pixels of the launch are a queue (64 positions per 8x8 tile, in
+    // the order of launch_render_generic), a wavefront takes as many positions as it has free lanes, with one atomic.
+    // A pixel's work is its own (its stream, its rays, its colour), whichever lane runs it, so pixels and
     // states are the same bits as with one fixed pixel per lane — but a wavefront no longer lasts as long as its longest
     // pixel (4 samples x 9 rays through glass against 4 rays of sky: the launch used to end with a few wavefronts of such
     // pixels on an idle chip).  Every wavefront leaves when the queue is exhausted and its lanes are done.
@@ -478,8 +480,10 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
             const unsigned long long want = __builtin_amdgcn_ballot_w64(!have);
             if (want == 0ull || exhausted) break;
             if (pool_next == pool_end) {
+                // as many positions as lanes are free, no more: a position held back for a lane that is still busy would start late
+                const unsigned n_want = (unsigned)__builtin_popcountll(want);
                 unsigned base = 0;
-                if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) base = atomicAdd(pixel_queue, 64u);
+                if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) base = atomicAdd(pixel_queue, n_want);
                 base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
                 if (base >= total) {
                     exhausted = true;
@@ -489,7 +493,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
                     continue;
                 }
                 pool_next = base;
-                pool_end = base + 64u;                                  // total is a multiple of 64
+                pool_end = min(base + n_want, total);
             }
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
             const unsigned q = pool_next + rank;
@@ -497,7 +501,8 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
                 // the queue is dealt out in chunks of 1 << chunk_log positions (whole rows of a tile) in a scattered order (chunk * mul mod
                 // n_chunks, mul coprime to n_chunks: host): the pixels a wavefront holds come from all over the frame, so the long
                 // pixels of one region (glass: 36 rays in sequence) are spread over all wavefronts instead of filling a few
-                const unsigned chunk = ((q >> chunk_log) * perm_mul) % (total >> chunk_log), within = q & ((1u << chunk_log) - 1u);
+                const unsigned chunk = ((q >> chunk_log) * perm_mul) % (total >> chunk_log);
+                const unsigned within = q & ((1u << chunk_log) - 1u);
                 const unsigned tile = chunk >> (6 - chunk_log), sub = chunk & ((1u << (6 - chunk_log)) - 1u);
                 const unsigned tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
                 const unsigned in_tile = (sub << chunk_log) + within;   // 0..63, row-major in the 8x8 tile
@@ -558,7 +563,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
 #ifdef CRT_TUNING
         ++tl_trips;
 #endif
-        const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode, stack, in_flight, coop);   // all lanes: the shared walk needs them
+        const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode, stack, in_flight, use_coop, coop_lds);   // all lanes: the shared walk needs them
         if (in_flight) {
             V3 L = V3{0.0f, 0.0f, 0.0f};
             bool done = true;
@@ -618,6 +623,17 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
     }
 }
 
+// ---- the order of the pixel queue ------------------------------------------------------------------------------
+// A pixel's cost is set by what its rays meet: behind glass `shade` follows 9 rays per sample one after the other, on a
+// Lambertian 2, on the sky 1 — and a wavefront's trip lasts as long as the sum of its rays' walks, so 64 pixels behind glass
+// in one wavefront are the longest chain there is.  The queue is therefore dealt out in chunks of 4 pixels of a row in a
+// scattered order (chunk c at place c * mul mod n_chunks): what a wavefront holds comes from all over the frame, expensive
+// regions are spread over all wavefronts and over the whole launch.  Measured against it on one box (tools/ab_env.sh) and
+// dropped: orders from a probe ray per 8x8 tile, per 4x4 block or per chunk (the material at its first hit; or only whether
+// the root's box is met: sky last) — most expensive first from one cursor, dealt like cards over the wavefronts' first
+// pools, or class 0 dealt statically (wavefront w renders S[w], S[w + W], ...): 7.7-11.6 ms against 5.9 ms — a queue that
+// starts with the expensive pixels fills EVERY wavefront with them, their trips are the longest possible, and the cheap nine
+// tenths of the frame wait behind them.
 hipError_t launch_render_generic(const RenderParams& p, const float* d_base, const float* d_shade_n, const int* d_material_of,
                                  const void* d_materials, int n_tris, const float4* d_nodes, int n_nodes, const float rot[9],
                                  uint32_t* d_state, float* d_rgb, bool bvh, bool fast, int shader, int max_depth, int force_mode,
@@ -656,24 +672,27 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
     if (const char* ev = getenv("CRT_GENERIC_BLOCKS")) resident = (unsigned)std::max(1, atoi(ev));   // resident blocks in total
 #endif
     dim3 block(256), grid((unsigned)std::min<unsigned long long>((tiles + 3) / 4, resident));
-    e = hipMemsetAsync(d_pixel_queue, 0, sizeof(unsigned), stream);
+    e = hipMemsetAsync(d_pixel_queue, 0, kGenericQueueWords * sizeof(unsigned), stream);   // [0] the queue's cursor
     if (e != hipSuccess) return e;
     // the order of the pixel queue: chunks of 4 positions, chunk c at place c * mul mod n_chunks (tools/sweep_queue.sh)
-    unsigned chunk_log = 2, perm_mul = 1;
+    unsigned chunk_log = kGenericChunkLog, perm_mul = 1;
 #ifdef CRT_TUNING
     if (const char* ev = getenv("CRT_QUEUE_CHUNK_LOG")) chunk_log = (unsigned)std::min(6, std::max(0, atoi(ev)));
 #endif
     {
         const unsigned long long n_chunks = tiles * 64ull >> chunk_log;
         static const unsigned primes[] = {1999u, 1997u, 1993u, 1987u, 1979u, 1973u, 1951u, 1949u};   // the first that does not divide n_chunks
-        for (unsigned pr : primes)
-            if (n_chunks % pr != 0ull && n_chunks * pr < 0xffffffffull) {
-                perm_mul = pr;
-                break;
-            }
+        unsigned first = 0;
 #ifdef CRT_TUNING
-        if (const char* ev = getenv("CRT_QUEUE_SCATTER")) if (atoi(ev) == 0) perm_mul = 1;
+        if (const char* ev = getenv("CRT_QUEUE_MUL")) first = (unsigned)std::max(0, atoi(ev));   // 0: the table; else this multiplier if coprime
+        if (first > 1 && n_chunks % first != 0ull && n_chunks * first < 0xffffffffull) perm_mul = first;
 #endif
+        if (perm_mul == 1 && first != 1)
+            for (unsigned pr : primes)
+                if (n_chunks % pr != 0ull && n_chunks * pr < 0xffffffffull) {
+                    perm_mul = pr;
+                    break;
+                }
     }
     hipLaunchKernelGGL(fn, grid, block, lds, stream, p, sc, b, d_state, d_rgb, shader, max_depth, force_mode, d_pixel_queue, walk_mode, coop_cap,
                        chunk_log, perm_mul);
