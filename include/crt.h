@@ -277,8 +277,9 @@ int crt_render_rows_ex(const crt_scene *scene, const crt_camera *camera, crt_rng
  * 4 entries on, each dealt out as 2, 4 or 8 row slabs to different blocks (test hook of the sub-item path); BVH world only: 1 = the per-ray tree walk instead of the tiled kernels, 5 = the walk's
  * general loop for every wavefront, 6 = the same with every direction chain iterated from its
  * fourth element, 7 = the tiled kernels with every lane on their general per-lane path (test hooks
- * for the rare paths), 9 = crt_render_rows_ex with the recursive shader walks the skip links of the flat node array instead of the
- * pair records (A/B).
+ * for the rare paths); crt_render_rows_ex with the recursive shader (default: the pair records, walked by the wavefront
+ * together): 9 = the skip links of the flat node array, 11 = the pair records with one stack per lane (A/B), 12 = the
+ * shared walk with a 96-item list (test hook: trips that overflow it are redone by the literal walk).
  * All variants produce identical pixels.  Returns the previous value. */
 int crt_set_kernel_variant(int variant);
 

@@ -50,12 +50,17 @@ while time.time() - t0 < budget:
     ref, states = oracle.render_ex(w, bvh, shader, ocam, nx, ny, spp, states, max_depth=depth)
     after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
     d = torch.zeros(ny * nx * 3, dtype=torch.float32, device="cuda")
+    # the walks of the generic kernel: 0 shared by the wavefront (default), 12 the same with a short list (abandoned trips),
+    # 11 one stack per lane, 9 skip links; 1: LambertShade / shade_normal through the generic kernel instead of the tiled ones
+    variant = (0, 0, 12, 11, 9)[seed % 5] if shader == api.SHADER_SHADE else (0, 1)[seed % 2]
+    prev = _lib.lib().crt_set_kernel_variant(variant)
     api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH if world == "bvh" else api.WORLD_LIST, shader=shader,
                        max_depth=depth)
     torch.cuda.synchronize()
+    _lib.lib().crt_set_kernel_variant(prev)
     got = d.cpu().numpy().reshape(ny, nx, 3)
     if not (same(got, ref) and np.array_equal(st.export()[1:], after[1:])):
-        print("MISMATCH seed %d: n=%d %dx%dx%d %s shader %d depth %d" % (seed, n, nx, ny, spp, world, shader, depth), flush=True)
+        print("MISMATCH seed %d: n=%d %dx%dx%d %s shader %d depth %d variant %d" % (seed, n, nx, ny, spp, world, shader, depth, variant), flush=True)
         sys.exit(1)
     n_cases += 1
     seed += 1
