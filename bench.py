@@ -325,6 +325,33 @@ def main():
                                "thrust::sort's sequential merge sort under a non-strict comparator (hitable/bvh.h:9-45,86-92)",
                      "ms_per_frame": ms_b, "Mrays/s": NX * NY * args.spp / ms_b / 1e3, "host_build_s": build_s}
 
+    # the recursive `shade` (core/render.h:48-67) with Lambertian / Metal / Dielectric / DiffuseLight dealt over
+    # the mesh in bands of 2 500 triangles, depth 8, BVH world, 4 samples per pixel (the workload of tools/shade_time.py and
+    # profiles/r3_f): the generic kernel.  Reported beside the headline, never as it.
+    f2_shade = None
+    if rank == 0 and world == 1 and tiled and not args.no_extras:
+        scene_f = api.Scene.from_obj(obj_path, scale=1.0)
+        st_f = api.SetCurandState(NX, NY, 0)
+        api.create_BVHfromList(scene_f, st_f)
+        mats = [(api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0), (api.METAL, (0.8, 0.85, 0.88), 0.1), (api.DIELECTRIC, (1, 1, 1), 1.5),
+                (api.DIFFUSE_LIGHT, (4.0, 4.0, 4.0), 0.0)]
+        scene_f.set_materials(mats, (np.arange(scene_f.n_triangles) // 2500 % 4).astype(np.int32))
+        buf = torch.empty(NX * NY * 3, dtype=torch.float32, device="cuda")
+        f_spp, f_depth = 4, 8
+        for _ in range(2):
+            api.render_rows_ex(scene_f, camera, st_f, NX, NY, f_spp, 0, NY, buf, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=f_depth, stream=stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            api.render_rows_ex(scene_f, camera, st_f, NX, NY, f_spp, 0, NY, buf, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=f_depth, stream=stream)
+        torch.cuda.synchronize()
+        ms_f = (time.perf_counter() - t1) / 5 * 1e3
+        f2_shade = {"what": "recursive shade, depth %d, 4 material classes in bands, BVH world, %d spp, same mesh and camera: render_generic_kernel "
+                            "(persistent wavefronts, pair walk shared by the wavefront)" % (f_depth, f_spp),
+                    "parity": "PARITY UNPINNED (in-repo oracle; pow(x, 5.0f) and the tree's shape by stated rules)",
+                    "ms_per_frame": ms_f, "M primary rays/s": NX * NY * f_spp / ms_f / 1e3}
+        scene_f.close()
+
     # The one-call surface crt_render(width, height, samples, list, camera) -> HOST RGB buffer: states restored from
     # the seed, the frame, 24.9 MB over PCIe into a pageable buffer.  Reported beside the resident figure, never as it.
     pcie = None
@@ -422,6 +449,7 @@ def main():
             "screen_filling_variant": filling,
             "second_workload": second,
             "bvh_world": bvh_world,
+            "f2_shade": f2_shade,
             "pcie_inclusive_one_call": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -950,10 +950,9 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
                                            t ? t->d_material_slots : scene->d_material_of, scene->d_materials, scene->n_tris,
                                            t ? t->d_nodes : nullptr, t ? t->n_nodes : 0, rot, rng->d_state, d_rgb, world == 1, fast,
                                            shader, max_depth, force_mode, stream,
-                                           // pair records for the incoherent secondary rays of `shade`; primary rays of one tile walk the
-                                           // same nodes and are a little faster over the skip links (variant 9: skip links everywhere;
-                                           // 11: one stack per lane; 12: the shared walk with a short list)
-                                           (t && shader == CRT_SHADER_SHADE) ? t->d_pairs : nullptr, t ? t->d_partner : nullptr,
+                                           // the pair records, walked by the wavefront together (variant 9: skip links; 11: one stack
+                                           // per lane; 12: the shared walk with a short list)
+                                           t ? t->d_pairs : nullptr, t ? t->d_partner : nullptr,
                                            g_variant == 9 ? 0 : (g_variant == 11 ? 1 : (g_variant == 12 ? 3 : 2)),
                                            cx.d_pixel_queue, cx.n_cus, g_d_stats));
         cx.ev_has_mid = false;

@@ -4,6 +4,7 @@
 which:  shade        recursive `shade`, depth 8, 4 materials, BVH world     (render.h:48-67; spp default 4)
         lambert4     LambertShade with the same 4 materials, BVH world       (render.h:70-87; spp default 4)
         lambert4_list  the same in the list world
+        lambert4_generic  LambertShade with the 4 materials, BVH world, through the generic kernel (variant 1)
         normal       shade_normal, BVH world                                 (render.h:90-103)
         bvh_walk     LambertShade, one Lambertian, BVH world, per-ray tree walk only (variant 1; spp default 4)
         bvh_tiled    LambertShade, one Lambertian, BVH world, tiled kernels  (the default path; spp default 64)
@@ -31,7 +32,7 @@ st = api.SetCurandState(nx, ny, 0)
 if which not in ("list", "lambert4_list"):
     api.create_BVHfromList(scene, st)
 n = scene.n_triangles
-if which in ("shade", "lambert4", "lambert4_list", "normal"):
+if which in ("shade", "lambert4", "lambert4_list", "lambert4_generic", "normal"):
     mats = [(api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0), (api.METAL, (0.8, 0.85, 0.88), 0.1), (api.DIELECTRIC, (1, 1, 1), 1.5),
             (api.DIFFUSE_LIGHT, (4.0, 4.0, 4.0), 0.0)]
     scene.set_materials(mats, (np.arange(n) // 2500 % 4).astype(np.int32))
@@ -44,6 +45,10 @@ def frame():
         api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=8, stream=s)
     elif which == "lambert4":
         api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_LAMBERT, max_depth=8, stream=s)
+    elif which == "lambert4_generic":
+        api.set_kernel_variant(1)
+        api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_LAMBERT, max_depth=8, stream=s)
+        api.set_kernel_variant(0)
     elif which == "lambert4_list":
         api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_LIST, shader=api.SHADER_LAMBERT, max_depth=8, stream=s)
     elif which == "normal":
