@@ -229,6 +229,46 @@ def test_gpu_lambert_materials_through_the_tiled_kernels_on_a_dense_pile(gpu, or
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", ["list", "bvh"])
+def test_gpu_generic_kernel_on_strip_sets_equals_the_full_frame(gpu, world):
+    """The generic kernel's pixel queue runs over the rows a launch owns: every rank's strip set (32-row strips dealt
+    round-robin, crt_render_strips / _bvh; a scene with materials, variant 1 = LambertShade through the generic kernel) is the
+    full frame's rows, pixels and RNG states — frames whose height is not a multiple of the strip or the tile height."""
+    from cudaraytracer_amd.dist import partition_strips
+    rng = np.random.RandomState(5)
+    n = 300
+    sc = scenes.random_soup(n, 5, extent=3.0, size=1.5)
+    of = rng.randint(0, len(MATS), n).astype(np.int32)
+    nx, ny, spp, ranks = 75, 213, 2, 3
+    c = sc["camera"]
+    scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+    st = api.SetCurandState(nx, ny, 0)
+    if world == "bvh":
+        api.create_BVHfromList(scene, st)
+    scene.set_materials(MATS, of)
+    full = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH if world == "bvh" else api.WORLD_LIST, api.SHADER_LAMBERT, 8, variant=1)
+    full_states = st.export()
+    prev = _lib.lib().crt_set_kernel_variant(1)
+    try:
+        for r in range(ranks):
+            strips = partition_strips(ny, ranks, r)
+            rows = sum(cnt for _, cnt in strips)
+            s = api.CurandState.for_strips(nx, ny, r, 32, ranks, 0)
+            piece = gpu.zeros(rows * nx * 3, dtype=gpu.float32, device="cuda")
+            api.render_strips(scene, cam, s, nx, ny, spp, r, 32, ranks, piece, stream=gpu.cuda.current_stream(), bvh=world == "bvh")
+            gpu.cuda.synchronize()
+            got = piece.cpu().numpy().reshape(rows, nx, 3)
+            want = np.concatenate([full[y0:y0 + cnt] for y0, cnt in strips], axis=0)
+            want_states = np.concatenate([full_states[y0 * nx:(y0 + cnt) * nx] for y0, cnt in strips], axis=0)
+            skip = 1 if (r == 0 and world == "bvh") else 0   # pixel 0's stream: the BVH build drew from the full frame's state[0]
+            assert same(got.reshape(-1, 3)[skip:], want.reshape(-1, 3)[skip:]), (world, r)
+            assert np.array_equal(s.export()[skip:], want_states[skip:]), (world, r)
+    finally:
+        _lib.lib().crt_set_kernel_variant(prev)
+
+
+@pytest.mark.gpu
 def test_gpu_shade_on_the_c3_mesh_matches_oracle_crops(gpu, oracle, tmp_path):
     """The generic kernel at the size the benchmarks use: BASELINE configs[2]'s mesh (100 000 triangles, OBJ round
     trip, reference camera), BVH world, all four material classes dealt over the triangles, recursive shade with
