@@ -681,7 +681,7 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
 #endif
     {
         const unsigned long long n_chunks = tiles * 64ull >> chunk_log;
-        static const unsigned primes[] = {1999u, 1997u, 1993u, 1987u, 1979u, 1973u, 1951u, 1949u};   // the first that does not divide n_chunks
+        static const unsigned primes[] = {1999u, 1997u, 1993u, 1987u, 997u, 991u, 499u, 491u, 251u, 241u, 127u, 113u, 61u, 59u};   // the first that does not divide n_chunks and keeps c * mul in 32 bits
         unsigned first = 0;
 #ifdef CRT_TUNING
         if (const char* ev = getenv("CRT_QUEUE_MUL")) first = (unsigned)std::max(0, atoi(ev));   // 0: the table; else this multiplier if coprime
