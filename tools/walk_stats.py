@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Lane occupancy of the generic kernel's loops on the shade workload (TUNING build: make -C cudaraytracer_amd/csrc tuning).
-    python3 tools/walk_stats.py [spp] [mesh]"""
+    python3 tools/walk_stats.py [spp] [mesh] [variant]      variant: 0 the shared walk (default), 11 one stack per lane, 9 skip links"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cudaraytracer_amd import api, scenes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 mesh = sys.argv[2] if len(sys.argv) > 2 else "C3"
+variant = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 path, nx, ny, _ = scenes.baseline_obj(mesh, tempfile.mkdtemp())
 scene = api.Scene.from_obj(path, scale=1.0)
 cam = api.init_camera(nx, ny); st = api.SetCurandState(nx, ny, 0)
@@ -15,6 +16,8 @@ n = scene.n_triangles
 mats = [(api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0), (api.METAL, (0.8, 0.85, 0.88), 0.1), (api.DIELECTRIC, (1, 1, 1), 1.5), (api.DIFFUSE_LIGHT, (4.0, 4.0, 4.0), 0.0)]
 scene.set_materials(mats, (np.arange(n) // 2500 % 4).astype(np.int32))
 d = torch.zeros(ny * nx * 3, dtype=torch.float32, device="cuda")
+api.set_kernel_variant(variant)
+print("shade, depth 8, 4 materials, BVH world, %s, %d spp, kernel variant %d" % (mesh, spp, variant))
 api.tiled_stats(1)
 api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=8, stream=torch.cuda.current_stream())
 torch.cuda.synchronize()
