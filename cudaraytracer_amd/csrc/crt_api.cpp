@@ -978,7 +978,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
             HIP_TRY(crt::launch_frame_prepass(scene->bvh->d_base_slots, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
             HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, 1, &cx.w,
                                        cx.n_cus, true, g_d_stats, timing ? cx.ev_mid : nullptr, &cx.cache_bvh, true, stream,
-                                       static_cast<const crt::BvhTiles*>(scene->bvh->d_tiles_view), g_variant == 7, materials));
+                                       &scene->bvh->tiles_view, g_variant == 7, materials));
             cx.ev_has_mid = true;
             if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
             cx.ev_valid = timing;

@@ -184,7 +184,6 @@ crt_bvh::~crt_bvh() {
     if (d_partner) (void)hipFree(d_partner);
     if (d_slot_leaf) (void)hipFree(d_slot_leaf);
     if (d_anc) (void)hipFree(d_anc);
-    if (d_tiles_view) (void)hipFree(d_tiles_view);
 }
 
 extern "C" {
@@ -385,7 +384,6 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
     if (e == hipSuccess) e = hipMalloc(&t->d_partner, partner.size() * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&t->d_slot_leaf, slot_leaf.size() * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&t->d_anc, anc.size() * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&t->d_tiles_view, sizeof(crt::BvhTiles));
     if (e == hipSuccess) e = hipMemcpy(t->d_partner, partner.data(), partner.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->d_slot_leaf, slot_leaf.data(), slot_leaf.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->d_anc, anc.data(), anc.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -394,7 +392,7 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
         view.nodes = t->d_nodes; view.n_nodes = t->n_nodes; view.partner = t->d_partner; view.slot_leaf = t->d_slot_leaf;
         view.anc = t->d_anc; view.anc_stride = t->anc_stride;
         memcpy(view.rot, rotm, sizeof rotm);
-        e = hipMemcpy(t->d_tiles_view, &view, sizeof view, hipMemcpyHostToDevice);
+        t->tiles_view = view;
     }
     if (e == hipSuccess && have_stream0) {   // the stream moved on by one draw per node
         const uint32_t w[6] = {b.rng.d, b.rng.v[0], b.rng.v[1], b.rng.v[2], b.rng.v[3], b.rng.v[4]};

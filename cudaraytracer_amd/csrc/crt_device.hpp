@@ -136,7 +136,17 @@ struct MatView {
     const MaterialPOD* materials = nullptr;  // null: the scene's single Lambertian (RenderParams::albedo)
     int normal_shader = 0;                   // != 0: shade_normal (render.h:90-103): a hit returns rec.normal, nothing is drawn
 };
-struct BvhTiles;
+// (a HOST struct of device pointers: launch_render hands it to the kernel by value)
+struct BvhTiles {
+    const float4* nodes;     // flat tree (crt_bvh_kernels.hpp)
+    int n_nodes;
+    const int* partner;      // per slot s: r(s) = s with the two slots of a 2-triangle leaf swapped.  The tree keeps, among equal t,
+                             // the LAST leaf and inside a leaf the FIRST triangle (bvh.h:172-179, hitable_list.h:84): the larger r wins.
+    const int* slot_leaf;    // per slot: leaf ordinal (bits 0..23) | leaf depth << 24
+    const int* anc;          // per leaf ordinal: node indices of the path root..leaf, anc_stride ints each
+    int anc_stride;
+    float rot[9];            // rotate(., 0) matrix
+};
 hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4* d_cls, int n_pad,
                          const float* d_shade_n, uint32_t* d_state, float* d_rgb, int variant,
                          const TiledWork* work, int n_cus, bool fast_rcp, unsigned long long* d_stats,
@@ -196,16 +206,6 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
 // a triangle is hit through the tree iff it passes Triangle::collision_detection AND the boxes of its
 // leaf and of all the leaf's ancestors pass AABB::hit — the tile lists (a superset of the first
 // condition) give the candidates, the chain of boxes is checked for the winner of every pixel.
-struct BvhTiles {
-    const float4* nodes;     // flat tree (crt_bvh_kernels.hpp)
-    int n_nodes;
-    const int* partner;      // per slot s: r(s) = s with the two slots of a 2-triangle leaf swapped.  The tree keeps, among equal t,
-                             // the LAST leaf and inside a leaf the FIRST triangle (bvh.h:172-179, hitable_list.h:84): the larger r wins.
-    const int* slot_leaf;    // per slot: leaf ordinal (bits 0..23) | leaf depth << 24
-    const int* anc;          // per leaf ordinal: node indices of the path root..leaf, anc_stride ints each
-    int anc_stride;
-    float rot[9];            // rotate(., 0) matrix
-};
 
 // One level of BVHNode::UpdateBVH: the nodes level_nodes[0..n_level) (all of one depth) recompute
 // their boxes from their triangles (leaves) or children (the deeper levels are already done).

@@ -113,7 +113,7 @@ struct crt_bvh {
     int* d_slot_leaf = nullptr;         // per slot: leaf ordinal | leaf depth << 24
     int* d_anc = nullptr;               // per leaf ordinal: node indices root..leaf, anc_stride ints (-1 padded)
     int anc_stride = 0;
-    void* d_tiles_view = nullptr;       // crt::BvhTiles on the device
+    crt::BvhTiles tiles_view{};         // what the tiled kernels' BVH mode needs of the tree (device pointers; passed by value)
     int* d_level_nodes = nullptr;       // node indices grouped by depth
     std::vector<int> level_offset;      // level d = d_level_nodes[level_offset[d] .. level_offset[d + 1])
     std::vector<int> slot_tri;          // slot -> triangle index of the list

@@ -1505,8 +1505,10 @@ template <bool VREC, int OCC, int WAVES, bool BVH = false, bool MAT = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
-                   TiledWork w, unsigned long long* __restrict__ stats_in, int dbg_repeat_in, const BvhTiles* __restrict__ bvh,
+                   TiledWork w, unsigned long long* __restrict__ stats_in, int dbg_repeat_in, BvhTiles bvh,
                    unsigned split_packed, MatView mv) {
+    // bvh by value: its pointers come with the kernel's arguments and are global memory to the compiler (loaded from a struct in
+    // device memory they were generic: 119 FLAT loads in the BVH mode — which cost nothing measurable, 1.16 against 1.17 ms)
     // diagnostics: stats_in[kStatsTimeline] != 0 selects the light-weight timeline (wave start/end times only), which
     // leaves the kernel's timing intact; otherwise the full counters (which roughly double the kernel time)
     const bool timeline = stats_in != nullptr && stats_in[kStatsTimeline] != 0ull;
@@ -1647,7 +1649,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         e_c[c] = (lane < n) ? (int)lst[swave + (64 * c + lane) * slice_waves] : 0;
                         stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, e_c[c], n, lane, x, gy, cc[c]);
                         if (!lane_valid) cc[c].lo = cc[c].hi = 0u;
-                        q_c[c] = (lane < n) ? (int)(((unsigned)e_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bvh->partner[e_c[c] & 0x7fffffff])) : 0;
+                        q_c[c] = (lane < n) ? (int)(((unsigned)e_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bvh.partner[e_c[c] & 0x7fffffff])) : 0;
                         __builtin_amdgcn_wave_barrier();
                     }
             }
@@ -1660,7 +1662,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             // 7.5 us a shared tile's sample took).
             int first_level_h = 0;
             if (BVH && !tree_tile && !skip_item) {
-                const BvhTiles& bt = *bvh;
+                const BvhTiles& bt = bvh;
                 const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
                 const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, tly0));
                 first_level_h = __builtin_amdgcn_readfirstlane(
@@ -1737,10 +1739,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             } else if (BVH && tree_tile) {
                 if (wave == 0) {
                     BvhView view;
-                    view.nodes = bvh->nodes;
-                    view.n_nodes = bvh->n_nodes;
+                    view.nodes = bvh.nodes;
+                    view.n_nodes = bvh.n_nodes;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) view.rot[k] = bvh->rot[k];
+                    for (int k = 0; k < 9; ++k) view.rot[k] = bvh.rot[k];
                     const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
                     render_pixel<true, false, false, false, MAT>(p, x, ly, shade_n, state, rgb, lane_valid, [&](V3 d1, V3, float& closest, int& hit_idx) {
                         V3 used;
@@ -1751,7 +1753,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 // Master wave, BVH mode: publishes c3 (what the triangles see on the hot chain), merges the slices' keys,
                 // checks the winner's chain of boxes; a lane off the hot chain or with an unreachable winner resolves its
                 // pixel alone from the tile's whole list (general_winner + chain_ok_general, excluding what fails).
-                const BvhTiles& bt = *bvh;
+                const BvhTiles& bt = bvh;
                 const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
                 const int first_level = first_level_h;   // the tile's reference path is in lpath[0] (this wave's)
                 int tl_sample_bvh = 0;   // timeline mode: (slices done, chains checked) per sample of the first blocks' first tile
@@ -1994,7 +1996,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         const int n0 = min(cnt, 64);
         Cand cand = {0u, 0u, 0u, 0u};
         if (BVH && desc.y != 0u) {
-            const BvhTiles& bt = *bvh;
+            const BvhTiles& bt = bvh;
             BvhView view;
             view.nodes = bt.nodes;
             view.n_nodes = bt.n_nodes;
@@ -2453,7 +2455,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (const char* e = getenv("CRT_SHADE_VREC")) vrec = atoi(e) != 0;
 #endif
     using ShadeFn = void (*)(RenderParams, const float*, const float4*, int, const float*, uint32_t*, float*, TiledWork, unsigned long long*, int,
-                             const BvhTiles*, unsigned, MatView);
+                             BvhTiles, unsigned, MatView);
     // log2 of the number of row slabs a heavy tile of each weight class (> 768, 512, 384, 256, 192, 128, 96, 64, heavy) is dealt
     // out as (shade_tiles_kernel: sub-items).  Measured (profiles/r3_tiled/sweep_split_*.txt): splitting the heaviest tiles
     // x2 .. x8 changes neither the full frame nor the slowest rank of an 8-way split, on either C3 mesh — what bounds a
@@ -2539,7 +2541,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)n_blocks), dim3((unsigned)group * 64), 0, stream, p, d_rec, d_cls, n_pad, d_shade_n,
-                       d_state, d_rgb, w, d_stats, dbg_repeat, d_bvh_tiles, split_packed, materials ? *materials : MatView{});
+                       d_state, d_rgb, w, d_stats, dbg_repeat, d_bvh_tiles ? *d_bvh_tiles : BvhTiles{}, split_packed, materials ? *materials : MatView{});
     return hipGetLastError();
 }
 
