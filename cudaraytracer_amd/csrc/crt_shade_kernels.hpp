@@ -9,7 +9,8 @@
 // DiffuseLight (material/material.h:57-161) over ConstantTexture (material/texture.h:12-22).
 // LambertShade on the single-Lambertian scene of add_mesh_withNormal is served by the specialised
 // kernels (tiled list path, BVH walk); everything else runs here:
-//   * lane = pixel, the sample loop and the bounce loop are serial per lane (RNG order);
+//   * persistent wavefronts, lane = one pixel at a time (taken from a queue over the launch's pixels); a pixel's samples and
+//     bounces are serial (RNG order), the BVH world's tree walks are shared by the wavefront (bvh_walk_coop);
 //   * `shade` is recursive in the reference: emitted + attenuation * shade(scattered, depth - 1).
 //     A material that scatters never emits (only DiffuseLight emits, and it never scatters), so a
 //     level that recursed contributes  0 + attenuation * (deeper result);  the bounce loop keeps the
@@ -395,7 +396,7 @@ __device__ __forceinline__ V3 sky_of(V3 d) {   // backgroundSky(d), render.h:41-
     return sky_from_unit(unit_vector(d));
 }
 
-// shader: 0 LambertShade, 1 shade, 2 shade_normal.  256 threads = four 8x8 pixel tiles.
+// shader: 0 LambertShade, 1 shade, 2 shade_normal.  Persistent blocks of four wavefronts.
 template <bool FAST, bool BVH>
 #ifndef CRT_GENERIC_OCC
 #define CRT_GENERIC_OCC 3   // waves per SIMD the register allocation aims at: the shared walk's LDS admits three blocks per CU
