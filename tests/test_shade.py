@@ -5,6 +5,8 @@ GPU (marked): the generic kernel against the oracle through crt_render_rows_ex.
 
 PARITY UNPINNED additionally at pow(1 - cosine, 5.0f) (schlick, material.h:25): CUDA's powf is not
 reproducible off-device; oracle and kernels form the fifth power in double and round once."""
+import os
+
 import numpy as np
 import pytest
 
@@ -56,7 +58,51 @@ def oracle_world(oracle, sc, of, nx, ny):
     return w, cam
 
 
+SHADE_GOLDEN = ["shade_spheres_64x36x3_d8", "shade_soup60_40x30x2_d8"]   # tools/make_golden.py: shade_goldens()
+
+
+def golden_shade_case(g):
+    sc, _ = material_scene(str(g["kind"]))
+    mats = [(int(m[0]), (float(m[1]), float(m[2]), float(m[3])), float(m[4])) for m in g["materials"]]
+    return sc, mats, g["material_of"].astype(np.int32), int(g["nx"]), int(g["ny"]), int(g["spp"]), int(g["depth"])
+
+
 # ------------------------------------------------------------------ oracle (CPU)
+@pytest.mark.parametrize("name", SHADE_GOLDEN)
+def test_oracle_shade_matches_golden(oracle, golden_dir, name):
+    """Regression pin of the oracle's recursive shade over the BVH world (pixels and RNG states of the committed fixture)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    sc, mats, of, nx, ny, spp, depth = golden_shade_case(g)
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    w.set_materials(mats, of)
+    c = sc["camera"]
+    cam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
+    states = oracle.fresh_states(nx, ny)
+    bvh = oracle.Bvh(w, states)
+    buf, states = oracle.render_ex(w, bvh, oracle.SHADER_SHADE, cam, nx, ny, spp, states, max_depth=depth)
+    assert same(buf, g["rgb"])
+    assert np.array_equal(np.concatenate([states["d"][:, None], states["v"]], axis=1), g["states_after"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SHADE_GOLDEN)
+def test_gpu_shade_matches_golden(gpu, golden_dir, name):
+    """The generic kernel against the committed fixture, every walk: shared by the wavefront (0), the same with a short list
+    (12), one stack per lane (11), skip links (9), and the general loops (5, 6)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    sc, mats, of, nx, ny, spp, depth = golden_shade_case(g)
+    c = sc["camera"]
+    for variant in (0, 12, 11, 9, 5, 6):
+        scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+        st = api.SetCurandState(nx, ny, 0)
+        api.create_BVHfromList(scene, st)
+        scene.set_materials(mats, of)
+        got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH, api.SHADER_SHADE, depth, variant)
+        assert same(got, g["rgb"]), (name, variant)
+        assert np.array_equal(st.export()[1:], g["states_after"][1:]), (name, variant)   # state[0]: DESIGN.md §1
+
+
 def test_oracle_shade_closed_forms(oracle):
     """One big triangle in front of the camera covering the image centre."""
     pts = np.array([[-50, -50, -5.5], [50, -50, -5], [0, 50, -4.5]], dtype=np.float32)

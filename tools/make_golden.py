@@ -134,7 +134,33 @@ def small_bunny():
     print("small_bunny", buf.shape, "hit pixels %d / %d" % (int(hit.sum()), nx * ny))
 
 
+SHADE_MATS = [(0, (0.73, 0.73, 0.73), 0.0), (0, (0.65, 0.05, 0.05), 0.0), (1, (0.8, 0.85, 0.88), 0.1), (2, (1.0, 1.0, 1.0), 1.5),
+              (3, (4.0, 4.0, 4.0), 0.0), (1, (0.7, 0.6, 0.5), 0.6)]   # (class: 0 Lambertian 1 Metal 2 Dielectric 3 DiffuseLight, albedo, fuzz / ref_idx)
+
+
+def shade_goldens():
+    """Row f2: the recursive shade (core/render.h:48-67) with the four material classes (material/material.h:57-161) over a
+    BVH world: two glass / metal / light spheres on a Lambertian ground (many bounces, total internal reflection) and the
+    96-triangle soup (triangles behind the eye, coincident ones); depth 8; pixels and RNG states of the oracle."""
+    from tests.test_shade import material_scene
+    for name, kind, nx, ny, spp, depth in (("shade_spheres_64x36x3_d8", "spheres", 64, 36, 3, 8), ("shade_soup60_40x30x2_d8", "soup", 40, 30, 2, 8)):
+        sc, of = material_scene(kind)
+        of = (of % len(SHADE_MATS)).astype(np.int32)
+        w = po.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        w.set_materials(SHADE_MATS, of)
+        cam = camera_of(sc, nx, ny)
+        states = po.fresh_states(nx, ny)
+        bvh = po.Bvh(w, states)
+        buf, states = po.render_ex(w, bvh, po.SHADER_SHADE, cam, nx, ny, spp, states, max_depth=depth)
+        after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), rgb=buf, states_after=after, material_of=of,
+                            materials=np.array([(k, a[0], a[1], a[2], f) for k, a, f in SHADE_MATS], dtype=np.float64),
+                            nx=nx, ny=ny, spp=spp, depth=depth, kind=kind)
+        print(name, buf.shape, "NaN %d, mean %.3f" % (int(np.isnan(buf).sum()), float(np.nanmean(buf))))
+
+
 if __name__ == "__main__":
+    shade_goldens()
     small_bunny()
     bvh_goldens()
     main()
