@@ -446,7 +446,8 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
     b.wave_steps = b.walk_stats ? &tl_steps[threadIdx.x >> 6] : nullptr;
     unsigned tl_trips = 0, tl_pixels = 0;
     const unsigned long long tl0 = b.walk_stats ? (unsigned long long)wall_clock64() : 0ull;   // 100 MHz
-    unsigned long long tl1 = 0ull;
+    unsigned long long tl1 = 0ull, tl_few = 0ull, tl_one = 0ull;   // first time with fewer than 16 pixels / with one pixel left (after the queue ran dry)
+    unsigned tl_trips_few = 0;
 #endif
     int x = 0, ly = 0, y = 0;
     long long si = 0;
@@ -552,6 +553,10 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
                     if (slot < (unsigned)kStatsWaveSlots) {   // per wavefront: start, queue empty, end, steps << 40 | trips << 20 | pixels
                         unsigned long long* w = b.walk_stats + kStatsWaveLog + 4 * (size_t)slot;
                         w[0] = tl0; w[1] = tl1; w[2] = tl2;
+                        if (slot < (unsigned)(kStatsSampleBlocks * kStatsSampleSlots)) {   // (the sample log's words, unused by this kernel)
+                            b.walk_stats[kStatsSampleLog + 2 * (size_t)slot] = tl_few ? tl_few : tl2;
+                            b.walk_stats[kStatsSampleLog + 2 * (size_t)slot + 1] = ((tl_one ? tl_one : tl2) << 16) | (unsigned long long)(tl_few ? tl_trips - tl_trips_few : 0u);
+                        }
                         w[3] = ((unsigned long long)tl_steps[threadIdx.x >> 6] << 40) | ((unsigned long long)tl_trips << 20) | tl_pixels;
                     }
                 }
@@ -563,6 +568,11 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
         walk_stat(b, 0, __builtin_amdgcn_ballot_w64(in_flight));
 #ifdef CRT_TUNING
         ++tl_trips;
+        if (b.walk_stats && exhausted) {
+            const int live = __builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
+            if (live < 16 && tl_few == 0ull) { tl_few = (unsigned long long)wall_clock64(); tl_trips_few = tl_trips; }
+            if (live <= 1 && tl_one == 0ull) tl_one = (unsigned long long)wall_clock64();
+        }
 #endif
         const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode, stack, in_flight, use_coop, coop_lds);   // all lanes: the shared walk needs them
         if (in_flight) {

@@ -30,6 +30,7 @@ api.tiled_stats(2)   # time stamps only, at full speed
 api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=8, stream=torch.cuda.current_stream())
 torch.cuda.synchronize()
 tl = api.wave_timeline(4096)
+sl = api.sample_timeline().reshape(-1, 2)
 s = api.tiled_stats(0)
 t0 = (~s[10]) & 0xffffffffffffffff
 w = max(1, s[13])
@@ -48,3 +49,14 @@ for q in (0, 10, 25, 50, 75, 90, 95, 98, 99, 99.5, 99.9, 100):
     i = order[min(len(order) - 1, int(q / 100 * len(order)))]
     print("  %5.1f %8.2f %8.2f %8d %6d %5d" % (q, end[i], empty[i], steps[i], trips[i], pix0[i]))
 print("%d wavefronts; sum of steps %d; ending after 5 ms: %d, after 8 ms: %d, after 10 ms: %d" % (len(tl), steps.sum(), (end > 5).sum(), (end > 8).sum(), (end > 10).sum()))
+# the drain of the first 1024 wavefronts: when fewer than 16 pixels were left, when one, how many trips after "fewer than 16"
+n1 = min(1024, len(tl))
+few = (sl[:n1, 0].astype(np.int64) - int(t0w)) / 1e5
+one = ((sl[:n1, 1] >> 16).astype(np.int64) - int(t0w)) / 1e5
+trips_after = sl[:n1, 1] & 0xffff
+e1 = end[:n1]
+o1 = np.argsort(e1)
+print("drain of wavefronts 0..%d, by end time: percentile  end ms  <16 pixels at ms  1 pixel at ms  trips after <16" % (n1 - 1))
+for q in (50, 90, 99, 100):
+    i = o1[min(n1 - 1, int(q / 100 * n1))]
+    print("  %5.1f %8.2f %8.2f %8.2f %6d" % (q, e1[i], few[i], one[i], trips_after[i]))
