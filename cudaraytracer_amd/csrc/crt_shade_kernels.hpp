@@ -448,6 +448,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
     const unsigned long long tl0 = b.walk_stats ? (unsigned long long)wall_clock64() : 0ull;   // 100 MHz
     unsigned long long tl1 = 0ull, tl_few = 0ull, tl_one = 0ull;   // first time with fewer than 16 pixels / with one pixel left (after the queue ran dry)
     unsigned tl_trips_few = 0;
+    unsigned long long tl_walk = 0ull;   // time inside trace_any
 #endif
     int x = 0, ly = 0, y = 0;
     long long si = 0;
@@ -549,6 +550,7 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
                     const unsigned long long tl2 = (unsigned long long)wall_clock64();
                     atomicMax(&b.walk_stats[8], tl1); atomicMax(&b.walk_stats[9], tl2); atomicMax(&b.walk_stats[10], ~tl0);
                     atomicAdd(&b.walk_stats[11], tl1 - tl0); atomicAdd(&b.walk_stats[12], tl2 - tl0); atomicAdd(&b.walk_stats[13], 1ull);
+                    atomicAdd(&b.walk_stats[14], tl_walk);   // [14] time inside the walks, summed over wavefronts
                     const unsigned slot = blockIdx.x * 4u + (threadIdx.x >> 6);
                     if (slot < (unsigned)kStatsWaveSlots) {   // per wavefront: start, queue empty, end, steps << 40 | trips << 20 | pixels
                         unsigned long long* w = b.walk_stats + kStatsWaveLog + 4 * (size_t)slot;
@@ -574,7 +576,13 @@ render_generic_kernel(RenderParams p, ShadeScene sc, BvhView b, uint32_t* __rest
             if (live <= 1 && tl_one == 0ull) tl_one = (unsigned long long)wall_clock64();
         }
 #endif
+#ifdef CRT_TUNING
+        const unsigned long long tl_w0 = b.walk_stats ? (unsigned long long)wall_clock64() : 0ull;
+#endif
         const HitInfo rec = trace_any<FAST, BVH>(sc, b, r_o, r_d, force_mode, stack, in_flight, use_coop, coop_lds);   // all lanes: the shared walk needs them
+#ifdef CRT_TUNING
+        if (b.walk_stats) tl_walk += (unsigned long long)wall_clock64() - tl_w0;
+#endif
         if (in_flight) {
             V3 L = V3{0.0f, 0.0f, 0.0f};
             bool done = true;

@@ -36,6 +36,7 @@ t0 = (~s[10]) & 0xffffffffffffffff
 w = max(1, s[13])
 print("waves %d: queue empty for the last wave after %.2f ms, last wave ends after %.2f ms; mean over waves: queue empty after %.2f ms, end after %.2f ms"
       % (s[13], (s[8] - t0) / 1e5, (s[9] - t0) / 1e5, s[11] / w / 1e5, s[12] / w / 1e5))
+print("time inside the walks (trace_any): %.1f %% of the wavefronts' lifetimes" % (100.0 * s[14] / max(1, s[12])))
 tl = tl[tl[:, 2] != 0]
 t0w = tl[:, 0].min()
 end = (tl[:, 2] - t0w) / 1e5
