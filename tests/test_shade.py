@@ -276,6 +276,31 @@ def test_gpu_lambert_materials_through_the_tiled_kernels_on_a_dense_pile(gpu, or
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", ["list", "bvh"])
+def test_gpu_generic_kernel_edge_frames(gpu, oracle, world):
+    """The pixel queue at its edges: frames smaller than a tile, one pixel, zero samples (0 / 0 = NaN pixels, states untouched),
+    against the oracle."""
+    sc, of = material_scene("soup")
+    for nx, ny, spp in ((1, 1, 2), (3, 2, 1), (9, 7, 0), (17, 5, 3)):
+        w, ocam = oracle_world(oracle, sc, of, nx, ny)
+        c = sc["camera"]
+        scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+        st = api.SetCurandState(nx, ny, 0)
+        states = oracle.fresh_states(nx, ny)
+        bvh = None
+        if world == "bvh":
+            api.create_BVHfromList(scene, st)
+            bvh = oracle.Bvh(w, states)
+        scene.set_materials(MATS, of)
+        ref, states = oracle.render_ex(w, bvh, oracle.SHADER_SHADE, ocam, nx, ny, spp, states, max_depth=4)
+        after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+        got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH if world == "bvh" else api.WORLD_LIST, api.SHADER_SHADE, 4)
+        assert same(got, ref), (world, nx, ny, spp)
+        assert np.array_equal(st.export()[1:], after[1:]), (world, nx, ny, spp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", ["list", "bvh"])
 def test_gpu_generic_kernel_on_strip_sets_equals_the_full_frame(gpu, world):
     """The generic kernel's pixel queue runs over the rows a launch owns: every rank's strip set (32-row strips dealt
     round-robin, crt_render_strips / _bvh; a scene with materials, variant 1 = LambertShade through the generic kernel) is the
