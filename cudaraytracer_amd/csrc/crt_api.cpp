@@ -932,6 +932,13 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     p.rny = 1.0f / (float)ny;
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
 
+    // BVH world, LambertShade on one Lambertian, where the tiled kernels do not apply (more than 2^22 triangles; a camera outside
+    // the binning's range) or variant 1 asks for a per-ray walk: the generic kernel's walk shared by the wavefront is twice as
+    // fast as render_bvh_kernel (1.3 against 2.4 ms per 4-spp C3 frame) — which stays for trees without pair records, for the
+    // literal arithmetic of unbounded scenes and for the test hooks 5 and 6.
+    if (!generic && world == 1 && scene->bvh->d_pairs != nullptr && scene->tiled_safe && scene->bvh->coords_not_tiny &&
+        (g_variant == 1 || ((g_variant == 0 || g_variant == 2) && !(tiled_ok && scene->n_tris <= (1 << 22)))))
+        generic = true;   // (a camera the fast arithmetic does not cover sends the generic kernel to its literal loops: below)
     if (generic) {
         // any shader, any materials (crt_shade_kernels.hpp); fast arithmetic under the same conditions as below
         bool fast = scene->tiled_safe && (world == 0 || scene->bvh->coords_not_tiny);

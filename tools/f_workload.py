@@ -6,7 +6,7 @@ which:  shade        recursive `shade`, depth 8, 4 materials, BVH world     (ren
         lambert4_list  the same in the list world
         lambert4_generic  LambertShade with the 4 materials, BVH world, through the generic kernel (variant 1)
         normal       shade_normal, BVH world                                 (render.h:90-103)
-        bvh_walk     LambertShade, one Lambertian, BVH world, per-ray tree walk only (variant 1; spp default 4)
+        bvh_walk     LambertShade, one Lambertian, BVH world, per-ray tree walk only (variant 1: the generic kernel's shared walk; spp default 4)
         bvh_tiled    LambertShade, one Lambertian, BVH world, tiled kernels  (the default path; spp default 64)
         list         LambertShade, one Lambertian, list world (what bench.py times; spp default 64)
 mesh:   C3 (default; the lat-long mesh) or C3B (subdivided bunny + ground grid)
