@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the tree walks on the C3 mesh: render_bvh_kernel (one Lambertian, per-ray walk over skip links) and the generic
+"""A/B of the tree walks on the C3 mesh: the per-ray walk of LambertShade on one Lambertian (variant 1; render_bvh_kernel's general loop: variant 5) and the generic
 kernel's walks for `shade` — shared by the wavefront (default), one stack per lane (variant 11), skip links (9) — and for
 LambertShade / shade_normal through the generic kernel (variant 1: the shared walk).   python tools/r3_walk_ab.py"""
 import os, sys, tempfile, time
@@ -47,7 +47,10 @@ for materials in (False, True):
     else:
         api.set_kernel_variant(1)
         ms = timed(lambda: api.render_rows(scene, cam, st, nx, ny, 4, 0, ny, d, stream=s, bvh=True))
-        print("render_bvh_kernel (variant 1: per-ray walk over skip links, one Lambertian), 4 spp: %.2f ms" % ms, flush=True)
+        print("per-ray walk (variant 1: the generic kernel, walk shared by the wavefront), one Lambertian, 4 spp: %.2f ms" % ms, flush=True)
+        api.set_kernel_variant(5)
+        ms = timed(lambda: api.render_rows(scene, cam, st, nx, ny, 4, 0, ny, d, stream=s, bvh=True))
+        print("render_bvh_kernel, its general loop for every wavefront (variant 5: IEEE divisions over the skip links), one Lambertian, 4 spp: %.2f ms" % ms, flush=True)
         api.set_kernel_variant(0)
         ms = timed(lambda: api.render_rows(scene, cam, st, nx, ny, 4, 0, ny, d, stream=s, bvh=True))
         print("tiled kernels, BVH mode (default), one Lambertian, 4 spp: %.2f ms" % ms, flush=True)
