@@ -106,6 +106,7 @@ Context* context_for(int device, hipStream_t stream) {
                 c->ev_has_mid = false;
                 c->cache = crt::LaunchCache{};
                 c->cache_bvh = crt::LaunchCache{};
+                c->cache_generic = crt::LaunchCache{};
             }
             return c;
         }
@@ -961,7 +962,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
                                            // per lane; 12: the shared walk with a short list)
                                            t ? t->d_pairs : nullptr, t ? t->d_partner : nullptr,
                                            g_variant == 9 ? 0 : (g_variant == 11 ? 1 : (g_variant == 12 ? 3 : 2)),
-                                           cx.d_pixel_queue, cx.n_cus, g_d_stats));
+                                           cx.d_pixel_queue, cx.n_cus, g_d_stats, &cx.cache_generic));
         cx.ev_has_mid = false;
         if (timing) HIP_TRY(hipEventRecord(cx.ev_stop, stream));
         cx.ev_valid = timing;

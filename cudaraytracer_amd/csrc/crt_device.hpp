@@ -124,6 +124,7 @@ constexpr int kCtrWords = (3 + kLightChunks) * kCtrLine;
 struct LaunchCache {
     const void* fn = nullptr;
     int resident = 0;
+    size_t lds = 0;   // dynamic LDS the query was made with (render_generic_kernel)
 };
 // crt_material (include/crt.h) as the kernels read it, and the per-triangle material view of a launch
 struct MaterialPOD {
@@ -199,7 +200,8 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
                                  const void* d_materials, int n_tris, const float4* d_nodes, int n_nodes, const float rot[9],
                                  uint32_t* d_state, float* d_rgb, bool bvh, bool fast, int shader, int max_depth, int force_mode,
                                  hipStream_t stream, const float4* d_pairs, const int* d_partner, int walk_mode, unsigned* d_pixel_queue, int n_cus,
-                                 unsigned long long* d_stats = nullptr);   // d_stats: tuning builds only (BvhView::walk_stats)
+                                 unsigned long long* d_stats = nullptr,    // d_stats: tuning builds only (BvhView::walk_stats)
+                                 LaunchCache* cache = nullptr);            // the occupancy query, kept per launch context
 // walk_mode (BVH world with pair records): 2 the wavefront shares the walk (bvh_walk_coop), 1 one stack per lane (bvh_walk_pairs),
 // 0 skip links, 3 the shared walk with a short list (test hook).  d_pixel_queue: kGenericQueueWords words of the launch context.
 // What the tiled kernels need of the tree to serve the BVH world's PRIMARY rays:

@@ -52,7 +52,7 @@ struct Context {
     size_t rec_cap = 0, cls_cap = 0; // in triangles
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;
     bool ev_has_mid = false, ev_valid = false;
-    crt::LaunchCache cache, cache_bvh;
+    crt::LaunchCache cache, cache_bvh, cache_generic;
     unsigned* d_pixel_queue = nullptr;   // render_generic_kernel's queue cursor (kGenericQueueWords)
 };
 

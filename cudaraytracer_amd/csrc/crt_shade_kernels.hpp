@@ -657,7 +657,7 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
                                  const void* d_materials, int n_tris, const float4* d_nodes, int n_nodes, const float rot[9],
                                  uint32_t* d_state, float* d_rgb, bool bvh, bool fast, int shader, int max_depth, int force_mode,
                                  hipStream_t stream, const float4* d_pairs, const int* d_partner, int walk_mode, unsigned* d_pixel_queue, int n_cus,
-                                 unsigned long long* d_stats) {
+                                 unsigned long long* d_stats, LaunchCache* cache) {
     if (p.row_count <= 0 || p.nx <= 0) return hipSuccess;
     ShadeScene sc;
     sc.base = d_base; sc.shade_n = d_shade_n; sc.material_of = d_material_of;
@@ -684,8 +684,14 @@ hipError_t launch_render_generic(const RenderParams& p, const float* d_base, con
     const unsigned long long tiles = (unsigned long long)((p.nx + 7) / 8) * (unsigned long long)((p.row_count + 7) / 8);
     if (tiles * 64ull >= 0xffff0000ull) return hipErrorInvalidValue;   // the queue cursor is 32 bits (a 65 000 x 65 000 frame)
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (cache && cache->fn == (const void*)fn && cache->lds == lds) {
+        per_cu = cache->resident;
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds);
+        if (e != hipSuccess) return e;
+        if (cache) { cache->fn = (const void*)fn; cache->lds = lds; cache->resident = per_cu; }
+    }
     unsigned resident = (unsigned)std::max(1, n_cus) * (unsigned)std::max(1, per_cu);
 #ifdef CRT_TUNING
     if (const char* ev = getenv("CRT_GENERIC_BLOCKS")) resident = (unsigned)std::max(1, atoi(ev));   // resident blocks in total
