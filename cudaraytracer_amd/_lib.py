@@ -1,4 +1,4 @@
-"""ctypes binding of libcrt_hip.so — one prototype per symbol declared in include/crt.h."""
+"""ctypes binding of libcrt_hip.so — one prototype per symbol declared in include/crt.h and include/crt_debug.h."""
 import ctypes as C
 import os
 import subprocess
@@ -49,7 +49,7 @@ def build_library(force=False, verbose=False):
     return _LIB
 
 
-# symbol -> (restype, argtypes); must list every function include/crt.h declares.
+# symbol -> (restype, argtypes); must list every function include/crt.h and include/crt_debug.h declare.
 _fp = C.POINTER(C.c_float)
 PROTOTYPES = {
     "crt_abi_version": (C.c_int, []),
@@ -110,6 +110,12 @@ PROTOTYPES = {
     "crt_multi_frame": (C.c_void_p, [C.c_void_p]),
     "crt_multi_device_count": (C.c_int, [C.c_void_p]),
     "crt_multi_free": (None, [C.c_void_p]),
+    "crt_debug_trace_rays": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _fp, _fp, C.POINTER(C.c_int), _fp,
+                                       C.POINTER(C.c_int), _fp, _fp]),
+    "crt_debug_box_hit": (C.c_int, [C.c_int, C.c_int, _fp, _fp, _fp, C.POINTER(C.c_int)]),
+    "crt_debug_box_op": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "crt_debug_thrust_sort": (C.c_int, [C.c_int, _fp, C.POINTER(C.c_int)]),
+    "crt_debug_force_stream_recycle": (C.c_int, [C.c_int]),
     "crt_write_png_rgba8": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "crt_encode_png_rgba8": (C.c_longlong, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_longlong]),
     "crt_to_rgba8": (None, [_fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),

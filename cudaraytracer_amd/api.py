@@ -380,6 +380,44 @@ def audit_tiles(scene, camera, nx, ny, samples, seed=0):
     return tuple(out)
 
 
+def trace_rays(scene, mode, origin, direction, arith=0):
+    """crt_debug_trace_rays (include/crt_debug.h): hit, t, list index, normal, point of caller-supplied rays through the
+    kernels' own device functions.  origin: 3 floats (modes 0, 2) or one per ray."""
+    d = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+    o = np.ascontiguousarray(origin, dtype=np.float32).reshape(-1, 3)
+    if mode in (0, 2):
+        if len(o) != 1:
+            raise CrtError(_lib.CRT_ERR_INVALID, "modes 0 and 2 take ONE origin (the camera's)")
+    elif len(o) != len(d):
+        o = np.ascontiguousarray(np.broadcast_to(o, d.shape), dtype=np.float32)
+    n = len(d)
+    hit, idx = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    t, nrm, pt = np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    ip = C.POINTER(C.c_int)
+    check(_lib.lib().crt_debug_trace_rays(scene.handle, int(mode), int(arith), n, _fp(o), _fp(d), hit.ctypes.data_as(ip), _fp(t),
+                                          idx.ctypes.data_as(ip), _fp(nrm), _fp(pt)))
+    return hit, t, idx, nrm, pt
+
+
+def box_hit(form, box6, origin, direction):
+    """crt_debug_box_hit: AABB::hit(r, 0.001, FLT_MAX) in the kernels' literal (0) or bounded-scene (1) form."""
+    b = np.ascontiguousarray(box6, dtype=np.float32).reshape(-1, 6)
+    o = np.ascontiguousarray(origin, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(len(b), np.int32)
+    check(_lib.lib().crt_debug_box_hit(int(form), len(b), _fp(b), _fp(o), _fp(d), out.ctypes.data_as(C.POINTER(C.c_int))))
+    return out
+
+
+def box_op(where, op, a6, b6):
+    """crt_debug_box_op: surrounding_box (op 0) / TransformAABB with the identity Transform (op 1); where 0 = host build, 1 = refit kernel."""
+    a = np.ascontiguousarray(a6, dtype=np.float32).reshape(-1, 6)
+    b = np.ascontiguousarray(b6, dtype=np.float32).reshape(-1, 6)
+    out = np.zeros_like(a)
+    check(_lib.lib().crt_debug_box_op(int(where), int(op), len(a), _fp(a), _fp(b), _fp(out)))
+    return out
+
+
 def set_kernel_variant(v):
     return _lib.lib().crt_set_kernel_variant(int(v))
 

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
@@ -55,6 +56,7 @@ namespace crt_host {
 
 namespace {
 std::mutex g_ctx_mu;
+std::condition_variable g_ctx_cv;     // release_context waits here until nobody holds a pin on its context
 std::vector<Context*> g_contexts;
 unsigned long long g_next_ctx_id = 1;
 thread_local unsigned long long g_last_ctx_id = 0;   // crt_last_kernel_ms / crt_last_kernel_times: last launch of this thread
@@ -90,12 +92,22 @@ void free_context_memory(Context* c) {   // device memory and events of a contex
 }
 }  // namespace
 
+int g_force_stream_recycle = 0;   // crt_debug_force_stream_recycle (guarded by g_ctx_mu where it is consumed)
+
+// Returns the context PINNED (Context::pins, under g_ctx_mu): release_context does not free a pinned context, so the
+// pointer stays valid until unpin_context — also for a caller that is still waiting for Context::mu.
 Context* context_for(int device, hipStream_t stream) {
     const unsigned long long sid = stream_id_of(stream);
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     for (Context* c : g_contexts)
         if (c->device == device && c->stream == stream) {
-            if (c->stream_id != sid) {
+            bool recycled = c->stream_id != sid;
+            if (g_force_stream_recycle > 0 && c->pins == 0) {
+                --g_force_stream_recycle;
+                recycled = true;
+            }
+            ++c->pins;
+            if (recycled) {
                 // the handle of a destroyed stream, handed out again: a new stream.  Nothing of the old one may still be
                 // running into the scratch (one device synchronisation, once per recycled handle); time stamps and the
                 // cached occupancy are dropped, the buffers are scratch without state between frames and stay.
@@ -116,20 +128,28 @@ Context* context_for(int device, hipStream_t stream) {
     c->device = device;
     c->stream = stream;
     c->stream_id = sid;
+    c->pins = 1;
     g_contexts.push_back(c);
     return c;
+}
+
+void unpin_context(Context* c) {
+    if (!c) return;
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if (--c->pins == 0) g_ctx_cv.notify_all();
 }
 
 int release_context(int device, hipStream_t stream) {
     Context* c = nullptr;
     {
-        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        std::unique_lock<std::mutex> lock(g_ctx_mu);
         for (size_t i = 0; i < g_contexts.size(); ++i)
             if (g_contexts[i]->device == device && g_contexts[i]->stream == stream) {
                 c = g_contexts[i];
-                g_contexts.erase(g_contexts.begin() + (long)i);
+                g_contexts.erase(g_contexts.begin() + (long)i);   // from here on nobody can look it up ...
                 break;
             }
+        if (c) g_ctx_cv.wait(lock, [&] { return c->pins == 0; });   // ... and whoever already had has let go of it
     }
     if (!c) return CRT_OK;
     hipError_t e;
@@ -144,10 +164,13 @@ int release_context(int device, hipStream_t stream) {
 }
 
 // the context crt_last_kernel_* refer to: still alive?  (crt_stream_release may have freed it)
-static Context* last_context_locked_lookup() {
+static Context* last_context_locked_lookup() {   // pinned like context_for's
     std::lock_guard<std::mutex> lock(g_ctx_mu);
     for (Context* c : g_contexts)
-        if (c->id == g_last_ctx_id) return c;
+        if (c->id == g_last_ctx_id) {
+            ++c->pins;
+            return c;
+        }
     return nullptr;
 }
 
@@ -864,6 +887,7 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
                     device, scene->device, rng->device);
     Context* cxp = context_for(device, stream);
     if (!cxp) return fail(CRT_ERR_NOMEM, "crt_render_rows: out of memory");
+    CtxPin pin(cxp);
     Context& cx = *cxp;
     std::lock_guard<std::mutex> lock(cx.mu);
     g_last_ctx_id = cxp->id;
@@ -1048,6 +1072,7 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     int device = 0;
     Context* cxp = (hipGetDevice(&device) == hipSuccess) ? context_for(device, nullptr) : nullptr;
     if (!cxp) { crt_rng_free(rng); return fail(CRT_ERR_HIP, "crt_debug_audit_tiles: no launch context"); }
+    CtxPin pin(cxp);
     Context& cx = *cxp;
     std::lock_guard<std::mutex> lock(cx.mu);
     int rc = ensure_workspace(cx, nx, ny, scene->n_tris);
@@ -1189,6 +1214,7 @@ int crt_last_kernel_times(float* ms3) {
     // launch stream of that call.
     if (!ms3) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: null output");
     Context* cx = last_context_locked_lookup();
+    CtxPin pin(cx);
     if (!cx || !cx->ev_valid) return fail(CRT_ERR_INVALID, "crt_last_kernel_times: no timed kernel launched on this thread (crt_set_kernel_timing)");
     std::lock_guard<std::mutex> lock(cx->mu);
     HIP_TRY(hipEventSynchronize(cx->ev_stop));

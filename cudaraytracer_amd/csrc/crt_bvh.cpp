@@ -172,6 +172,22 @@ struct Builder {
 
 }  // namespace
 
+// crt_debug.h hooks onto the build's own helpers (tests/test_ref_thrust.py, tests/test_ref_hit.py)
+namespace crt_host {
+void debug_thrust_sort(int* order, int n, const float* key) {
+    std::vector<int> temp((size_t)std::max(n, 1));
+    thrust_sequential_sort(order, n, key, temp.data());
+}
+void debug_host_box_op(int op, const float* a6, const float* b6, float* out6) {
+    float m[9];
+    rotation_zero_matrix(m);
+    Box a, b;
+    for (int k = 0; k < 3; ++k) { a.mn[k] = a6[k]; a.mx[k] = a6[3 + k]; b.mn[k] = b6[k]; b.mx[k] = b6[3 + k]; }
+    const Box r = op == 0 ? surrounding(a, b) : transform_aabb(m, a);
+    for (int k = 0; k < 3; ++k) { out6[k] = r.mn[k]; out6[3 + k] = r.mx[k]; }
+}
+}  // namespace crt_host
+
 crt_bvh::~crt_bvh() {
     if (d_nodes) (void)hipFree(d_nodes);
     if (d_pairs) (void)hipFree(d_pairs);
@@ -294,7 +310,9 @@ int crt_scene_build_bvh(crt_scene* s, crt_rng* rng, uint64_t seed) {
         for (int slot = 0; slot < n; ++slot) {
             const float* nr = s->h_base.data() + (size_t)b.order[slot] * crt::kBaseFloats + 9;
             const double len = std::sqrt((double)nr[0] * nr[0] + (double)nr[1] * nr[1] + (double)nr[2] * nr[2]);
-            if (!(len > 0.0) || !std::isfinite(len)) { bad[slot] = 1; continue; }
+            // ... nor do normals whose float products d_k * n_k can underflow or overflow: the reference's float dot product of
+            // a subnormal-sized normal rounds to +-0 (`< 0` false: the triangle IS tested) whatever the exact sign says
+            if (!(len >= 7.888609052210118e-31) || !(len <= 1.2676506002282294e30)) { bad[slot] = 1; continue; }   // 2^-100 .. 2^100
             for (int k = 0; k < 3; ++k) un[(size_t)slot * 3 + k] = nr[k] / len;
         }
         // Normal cone of a subtree as one word: axis as three signed bytes / 127, threshold byte T = byte * kConeScale.  The walk

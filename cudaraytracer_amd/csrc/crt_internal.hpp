@@ -3,6 +3,7 @@
 #pragma once
 
 #include "../../include/crt.h"
+#include "../../include/crt_debug.h"
 #include "crt_device.hpp"
 
 #include <math.h>
@@ -44,6 +45,7 @@ struct Context {
     hipStream_t stream = nullptr;
     unsigned long long stream_id = 0;   // hipStreamGetId at creation
     std::mutex mu;                   // host-side: two threads enqueueing on the same stream
+    int pins = 0;                    // holders of a pointer from context_for (guarded by the context table's mutex)
     crt::TiledWork w{};
     size_t pool_entries = 0, tiles = 0, log_entries = 0;
     int n_cus = 0;
@@ -56,7 +58,15 @@ struct Context {
     unsigned* d_pixel_queue = nullptr;   // render_generic_kernel's queue cursor (kGenericQueueWords)
 };
 
-Context* context_for(int device, hipStream_t stream);
+Context* context_for(int device, hipStream_t stream);   // PINNED: pair every call with unpin_context (CtxPin)
+void unpin_context(Context* c);
+struct CtxPin {                      // scope guard of a pinned context
+    Context* c;
+    explicit CtxPin(Context* c_) : c(c_) {}
+    ~CtxPin() { unpin_context(c); }
+    CtxPin(const CtxPin&) = delete;
+    CtxPin& operator=(const CtxPin&) = delete;
+};
 // frees the context of (device, stream) if there is one (the stream is synchronised first); CRT_OK either way
 int release_context(int device, hipStream_t stream);
 void release_onecall(int device);   // what crt_render keeps per device
@@ -64,6 +74,9 @@ int ensure_records(Context& cx, int n_tris, int n_pad);
 int ensure_workspace(Context& ws, int nx, int rows, int n_tris);
 bool have_device();
 void rotation_zero_matrix(float m[9]);
+void debug_thrust_sort(int* order, int n, const float* key);                     // crt_bvh.cpp: the build's sort
+void debug_host_box_op(int op, const float* a6, const float* b6, float* out6);   // crt_bvh.cpp: the build's box helpers
+extern int g_force_stream_recycle;                                               // crt_api.cpp: crt_debug_force_stream_recycle
 
 // ---------------------------------------------------------------- host vec3 helpers
 struct H3 {

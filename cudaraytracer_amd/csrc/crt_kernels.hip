@@ -2816,5 +2816,6 @@ hipError_t launch_assemble_strips(const float* d_parts, long long part_stride, i
 }
 
 #include "crt_shade_kernels.hpp"
+#include "crt_debug_kernels.hpp"   // parity hooks of include/crt_debug.h: not on a render path
 
 }  // namespace crt

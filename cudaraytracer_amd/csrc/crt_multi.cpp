@@ -15,6 +15,7 @@
 // RCCL is bound at first use with dlopen (librccl.so.1 — the copy the process already holds, if
 // any — so the library itself loads on hosts without RCCL and fails loudly only here).
 #include "../../include/crt.h"
+#include "../../include/crt_debug.h"
 #include "crt_device.hpp"
 
 #include <dlfcn.h>
@@ -322,10 +323,19 @@ crt_multi* crt_multi_create(const float* points, int n_points, const float* idx3
     return m;
 }
 
-int crt_multi_update_pose(crt_multi* m, const float* new_points, int n_points) {
-    if (!m || !new_points) return fail(CRT_ERR_INVALID, "crt_multi_update_pose: null argument");
+namespace {
+// the CALLING thread's per-thread settings, handed to the workers with the job (the setters return the previous value)
+void read_caller_settings(crt_multi* m) {
     m->job_variant = crt_set_kernel_variant(0);
     crt_set_kernel_variant(m->job_variant);
+    m->job_timing = crt_set_kernel_timing(1);
+    crt_set_kernel_timing(m->job_timing);
+}
+}  // namespace
+
+int crt_multi_update_pose(crt_multi* m, const float* new_points, int n_points) {
+    if (!m || !new_points) return fail(CRT_ERR_INVALID, "crt_multi_update_pose: null argument");
+    read_caller_settings(m);
     m->job_camera = nullptr;
     m->job_points = new_points;
     m->job_n_points = n_points;
@@ -356,10 +366,7 @@ int crt_multi_render(crt_multi* m, const crt_camera* camera, int samples, int ma
     m->job_camera = camera;
     m->job_points = nullptr;
     m->job_samples = samples; m->job_max_depth = max_depth; m->job_frame = frame_index;
-    m->job_variant = crt_set_kernel_variant(0);          // read the calling thread's settings (the setters return the previous value)
-    crt_set_kernel_variant(m->job_variant);
-    m->job_timing = crt_set_kernel_timing(1);
-    crt_set_kernel_timing(m->job_timing);
+    read_caller_settings(m);
     int rc = run_job(m);                       // every device has its strips enqueued on its stream
     m->job_camera = nullptr;
     if (rc != CRT_OK) {                        // some device failed to enqueue: the others have work in flight — drain it

@@ -23,8 +23,9 @@
  *     — are independent; renders on one stream are ordered by the stream.  One crt_rng must not
  *     be in flight on two streams at once (its states are advanced in place), and
  *     crt_scene_update_pose must be ordered by the caller against renders of that scene on
- *     OTHER streams (same stream: ordered by the stream).  crt_last_error, crt_last_kernel_*,
- *     crt_set_kernel_variant and crt_debug_tiled_stats are per calling thread.
+ *     OTHER streams (same stream: ordered by the stream).  crt_last_error (and the diagnostics of
+ *     crt_debug.h: crt_last_kernel_*, crt_set_kernel_variant, crt_debug_tiled_stats) are per calling thread.
+ *   - diagnostics, A/B switches, timing hooks and parity hooks are declared in crt_debug.h, not here.
  *   - "bit-exact" in this file means: identical to the in-repo CPU oracle (oracle/), which is
  *     a restatement of the reference and is PARITY UNPINNED (no reference fixtures exist and
  *     the reference cannot be built here; see oracle/crt_oracle.h).
@@ -226,10 +227,6 @@ int crt_render_rows_bvh(const crt_scene *scene, const crt_camera *camera, crt_rn
 int crt_render_strips_bvh(const crt_scene *scene, const crt_camera *camera, crt_rng *rng, int nx,
                           int ny, int samples, int max_depth, int frame_index, int first_strip,
                           int strip_rows, int strip_step, float *d_rgb, void *stream);
-/* Diagnostics: the tree as it is on the device.  boxes6: n_nodes x {min xyz, max xyz}; meta4:
- * n_nodes x {skip, first slot, triangle count (0 = inner node), depth}, nodes in preorder;
- * slot_triangle: n_tris list indices in leaf order.  Any pointer may be NULL. */
-int crt_debug_bvh_export(const crt_scene *scene, float *boxes6, int *meta4, int *slot_triangle);
 /* replaces: writeCSV("output.csv", data) (Loader/CSVWriter.h:8-32) with the rows main() and
  * renderBVHAnimation collect (kernel.cu:61,18,37; core/render.h:232): header
  * frame,rendering,update,build; one row with the build time; one row per frame with the render
@@ -268,105 +265,16 @@ int crt_render_rows_ex(const crt_scene *scene, const crt_camera *camera, crt_rng
                        int samples, int max_depth, int frame_index, int row_begin, int row_count,
                        int world, int shader, float *d_rgb, void *stream);
 
-/* Kernel selection (diagnostics / A-B benchmarking), per calling thread. 0 = auto (default:
- * tiled when the scene and camera are finite and |coordinate| <= 2^38, else brute force),
- * 1 = brute-force list walk, 2 = tiled, 3 = tiled with a tiny survivor pool and heavy-tile
- * threshold (test hook for the overflow fallback and the shared-tile path), 4 = tiled with
- * scalar-operand (SGPR) list walks instead of the LDS-staged records and per-pixel candidate
- * masks (A/B), 8 = tiled with a 16-record binning log (test hook for its overflow fallback), 10 = tiled with shared tiles from
- * 4 entries on, each dealt out as 2, 4 or 8 row slabs to different blocks (test hook of the sub-item path); BVH world only: 1 = the per-ray tree walk instead of the tiled kernels, 5 = the walk's
- * general loop for every wavefront, 6 = the same with every direction chain iterated from its
- * fourth element, 7 = the tiled kernels with every lane on their general per-lane path (test hooks
- * for the rare paths); crt_render_rows_ex with the recursive shader (default: the pair records, walked by the wavefront
- * together): 9 = the skip links of the flat node array, 11 = the pair records with one stack per lane (A/B), 12 = the
- * shared walk with a 96-item list (test hook: trips that overflow it are redone by the literal walk).
- * All variants produce identical pixels.  Returns the previous value. */
-int crt_set_kernel_variant(int variant);
-
-/* Diagnostics of the tiled variant, per calling thread.  out48 (nullable, 48 words) first
- * receives the counters accumulated since the last enable:
- *   binning: [0] wavefronts that found work, [1] regions they entered, [2] tiles box-tested
- *   (64 per triangle and region in the lane = tile mode), [3] (wavefront, tile) pairs with survivors,
- *   [4] tiles, [5] sum and [6] max of the tile survivor count, [7] pool overflows,
- *   [8..23] histogram of the tile survivor count (bucket b: 2^(b-1) <= n < 2^b),
- *   shading kernel cycles (s_memtime): [24] heavy phase summed over blocks, [25] its max,
- *   [26] light phase summed over waves, [27] its max, [28] max wave total,
- *   busiest binning wavefront: [29] regions entered, [30] tiles box-tested, [31] cycles;
- *   master wave of shared tiles: [32] set-up+merge+shade, [33] own trace, [34] wait at the
- *   second barrier (cycles summed over [35] tiles with [36] survivors in total);
- *   per-pixel candidate masks of the light tiles with geometry: [37] tiles, [38] their list
- *   entries, [39] sum of the longest per-pixel candidate list of each, [40] sum of all lists,
- *   [41] tiles whose (pixel, entry) pairs did not fit the pair buffer, [42] pairs of the others.
- * Then enable != 0 (re)starts counting, enable == 0 stops it.  Counting costs atomics and clock
- * reads that slow the kernels down (binning 7x, shading 1.4x); enable == 2 selects the TIMELINE
- * mode instead: the shading kernel runs at full speed and every wavefront stores three time
- * stamps of the device-wide 100 MHz clock (start, end of the shared-tile phase, end) and
- * (entries << 44 | tile index << 20 | HW_REG_HW_ID[19:0]) of its block's last shared tile, read with
- * crt_debug_wave_timeline (4 words per wavefront, index = block * waves per block + wave; returns
- * the number of wavefront slots copied, at most max_waves).  max_waves == -1 reads the per-sample
- * log of blocks 0..3 instead (their first shared tile, list world): 4 x 256 pairs of time stamps
- * (master's draws done, slices done); `out` then holds 2048 words. */
-int crt_debug_tiled_stats(int enable, uint64_t *out48);
-int crt_debug_wave_timeline(uint64_t *out, int max_waves);
-
-/* Audit of the tiled variant's binning (full nx x ny image on the current device): a brute-
- * force kernel tests every triangle against `samples` rays of every pixel (pixel-corner jitter
- * included) and checks that each (ray, triangle) pair passing Triangle::collision_detection —
- * closest hit or not — has its triangle in the tile's survivor list AND passes the shading
- * kernel's per-pixel candidate test for its pixel.  out4[0] = passing pairs seen, out4[1] = pairs
- * whose triangle is missing from the list or from the pixel's candidates (must be 0), out4[2] =
- * "cull-sure" verdicts (tile or pixel) that saw dot(d, normal) < 0 (must be 0), out4[3] = last
- * offender (tile << 32 | triangle). */
-int crt_debug_audit_tiles(const crt_scene *scene, const crt_camera *camera, int nx, int ny,
-                          int samples, uint64_t seed, uint64_t *out4);
-
-/* Self-check: the kernels compute f = 1.0/a (shapes/triangle.h:80) as v_rcp_f32 + one Newton
- * step when the scene is bounded (|coordinate| <= 2^38, so 2^-20 <= |a| <= 2^84 wherever f
- * is used).  This compares that sequence with the IEEE quotient for EVERY float whose biased
- * exponent lies in [exp_lo, exp_hi], both signs, on the current device; *mismatches must be 0
- * for [27, 227] (2^-100 .. 2^100). */
-int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t *mismatches);
-/* Same idea for the quotients of the shading kernel (`x / len` in unit_vector,
- * `(x + U) / float(nx)`), computed as q0 = x*y, r = fma(-q0, b, x), q = fma(r, y, q0) with
- * y = the reciprocal above.  mode 0 = the check above; mode 1 = exhaustive over significands:
- * divisors 1.mb for mb in chunks [exp_lo, exp_hi] of 64 (2^17 divisors each) against ALL 2^23
- * numerator significands (chunks 0..63 = 7.04e13 pairs = every pair of significands);
- * mode 2 = every float divisor with biased exponent in [exp_lo, exp_hi], 64 pseudo-random
- * numerators each, exponents up to 60 below the divisor's, both signs; mode 3 = the kernel's
- * square root of normal floats (v_sqrt_f32 + neighbour residuals) against sqrtf for every positive
- * float with biased exponent in [exp_lo, exp_hi]. */
-int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t *mismatches);
-
-/* One core/vec3.h operation at a time on arrays (a, b, out: n x 3 floats, s: n floats; host pointers): where = 0 the
- * host layer's helpers (camera constructor, scene pack, BVH build: ops 1 sub, 3 s*a, 7 cross, 10 unit_vector,
- * 14 rotate), where = 1 the kernels' device functions (ops 1, 3, 6 dot, 7, 8 length, 10, 11 sky lerp of t = s,
- * 12 clip, 13 a /= s, and the fast forms 100 unit_vector_fast, 101 its y alone, 102 sky_from_unit).  Op codes are
- * those of oracle/ref_vec3.cpp, which wraps the reference's own core/vec3.h (replaces: core/vec3.h:73-217);
- * tests/test_vec3_ref.py compares bit for bit.  CRT_ERR_UNSUPPORTED for an operation that side does not have. */
-int crt_debug_vec3(int where, int op, long long n, const float *a, const float *b, const float *s, float *out);
-
-/* Duration in milliseconds of the last crt_render_rows main kernel launched through this
- * library on the calling thread, measured with HIP events on the launch stream.
- * Synchronises on that stream.  Negative on error. */
-float crt_last_kernel_ms(void);
-
-/* Same measurement split per kernel: ms3[0] = total, ms3[1] = binning kernel (0 for the
- * brute-force variant), ms3[2] = shading / brute-force kernel. */
-int crt_last_kernel_times(float *ms3);
-
-/* The three HIP events per frame behind crt_last_kernel_ms / crt_last_kernel_times (per calling
- * thread, default on).  Each is a marker packet between the frame's five kernels; a host that never
- * asks for kernel times can switch them off (bench.py does for its timed region: -7 us per frame).
- * While off, crt_last_kernel_* fail with CRT_ERR_INVALID.  Returns the previous value. */
-int crt_set_kernel_timing(int enable);
-
 /* Launch contexts.  Everything a render launch writes besides its outputs belongs to a context keyed by (current
  * device, stream), created at the first launch on that stream and grown with the frames it sees (at 1920x1080 and
  * 100 000 triangles: about 40 MB).  A host that creates streams as it goes calls this BEFORE hipStreamDestroy (no
  * launch of this library may be in progress on the stream from another thread): the stream is synchronised and its
  * context freed.  stream = NULL releases the default stream's context and what crt_render keeps.  CRT_OK also when
- * there is nothing to release.  A stream handle the runtime hands out again after a destroy is recognised by
- * hipStreamGetId and gets a fresh context state; crt_multi_free releases the contexts of its own streams. */
+ * there is nothing to release.  A host that destroys a stream WITHOUT this call leaves its context behind; when the
+ * runtime later hands the same handle to a new stream, the library notices only where the process's HIP runtime has
+ * hipStreamGetId (HIP >= 7.1; looked up at run time — PyTorch 2.10's bundled 7.0 runtime does not have it, there the old
+ * context is simply reused, which is safe as long as the old stream had drained) and then gives the handle a fresh
+ * context state.  crt_multi_free releases the contexts of its own streams. */
 int crt_stream_release(void *stream);
 
 /* ---- multi-GPU ------------------------------------------------------------------
@@ -398,17 +306,12 @@ int crt_gather_strips(const float *d_piece, int nx, int ny, int strip_rows, int 
                       float *d_parts, int64_t part_stride, float *d_full, void *nccl_comm,
                       void *stream);
 
-/* Test hook: the next `count` ncclSend calls made by this library (crt_gather_strips, crt_multi_render) report
- * ncclInternalError without reaching RCCL, so that the error paths of the exchange step can be exercised on one
- * device.  Returns the previous count; 0 switches it off. */
-int crt_debug_inject_send_failure(int count);
-
 /* One process, n_gpus devices (devices 0..n_gpus-1): the scene is replicated, every device gets
  * its strip set's RNG states (seed, stream = global pixel index), a stream and a host worker
  * thread; communicators come from ncclCommInitAll.  replaces: the driver shape of
  * renderListAnimation (core/render.h:159-189) for n_gpus devices.
  * crt_multi_render / crt_multi_update_pose hand the CALLING thread's crt_set_kernel_variant and
- * crt_set_kernel_timing settings to the workers for that job (the workers' own crt_last_kernel_* are not
+ * crt_set_kernel_timing settings (crt_debug.h) to the workers for that job (the workers' own crt_last_kernel_* are not
  * reachable: time a multi-device frame from outside).  Every exit of crt_multi_render — success, a device that
  * failed to enqueue, an RCCL error inside the grouped exchange — leaves the NCCL group closed, all of the
  * renderer's streams idle and the caller's device current.  crt_multi_free releases the launch contexts of its

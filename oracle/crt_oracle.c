@@ -544,6 +544,17 @@ static void thrust_seq_sort(int *first, int n, const float *key, int *temp) { /*
     if (!ping) memcpy(first, temp, (size_t)n * sizeof(int));
 }
 
+/* the restatement above on a key array (tests/test_ref_thrust.py holds it to rocThrust's thrust::sort) */
+int o_thrust_sort(int n, const float *key, int *order) {
+    if (n < 0) return -1;
+    if (n == 0) return 0;
+    int *temp = (int *)malloc((size_t)n * sizeof(int));
+    if (!temp) return -1;
+    thrust_seq_sort(order, n, key, temp);
+    free(temp);
+    return 0;
+}
+
 static o_transform identity_transform(void) {                              /* Transform::ResetTransform, transform.h:16-20 */
     o_transform t; t.position = v1(0); t.rotation = v1(0); t.scale = v1(1); return t;
 }
@@ -712,6 +723,114 @@ int o_bvh_hit(const o_bvh *bvh, const float origin[3], const float direction[3],
     if (index_out) *index_out = flag ? idx : -1;
     if (normal_out) { normal_out[0] = rec.normal.e[0]; normal_out[1] = rec.normal.e[1]; normal_out[2] = rec.normal.e[2]; }
     return flag;
+}
+
+/* ------------------------------------------------------------------ batch forms for tests/test_ref_hit.py
+ * (the reference's own headers answer the same questions on the GPU: oracle/ref_hit.hip) */
+
+/* `levels` more HitableList(1) wrappers around the world list, each one more Hitable::hit level (hitable.h:29-38):
+ * TransformRay on the way in (identity Transform: ScaleRay re-normalises), rotate(rec.normal, 0) on the way out; the
+ * wrapper's own collision_detection accepts its one element's hit iff tmp_rec.t < closest_so_far (hitable_list.h:84) */
+int o_world_hit_many(const o_world *world, int levels, long long n, const float *origin, const float *direction,
+                     int *hit, float *t_out, int *index_out, float *normal_out, float *p_out) {
+    const o_transform id = identity_transform();
+    for (long long i = 0; i < n; i++) {
+        o_ray r = make_ray(v3(origin[3 * i], origin[3 * i + 1], origin[3 * i + 2]),
+                           v3(direction[3 * i], direction[3 * i + 1], direction[3 * i + 2]), 0.0f);
+        for (int l = 0; l < levels; l++) r = TransformRay(&id, &r);
+        o_hitrec rec;
+        memset(&rec, 0, sizeof rec);
+        int idx = -1;
+        int flag = world_hit(world, &r, 0.001f, FLT_MAX, &rec, &idx);
+        for (int l = 0; l < levels; l++) {
+            if (flag && !(rec.t < (double)FLT_MAX)) flag = 0;
+            rec.normal = rotate(rec.normal, id.rotation);
+        }
+        hit[i] = flag;
+        t_out[i] = rec.t;
+        index_out[i] = flag ? idx : -1;
+        for (int c = 0; c < 3; c++) { normal_out[3 * i + c] = rec.normal.e[c]; p_out[3 * i + c] = rec.p.e[c]; }
+    }
+    return 0;
+}
+
+int o_bvh_hit_many(const o_bvh *bvh, long long n, const float *origin, const float *direction,
+                   int *hit, float *t_out, int *index_out, float *normal_out, float *p_out) {
+    for (long long i = 0; i < n; i++) {
+        o_ray r = make_ray(v3(origin[3 * i], origin[3 * i + 1], origin[3 * i + 2]),
+                           v3(direction[3 * i], direction[3 * i + 1], direction[3 * i + 2]), 0.0f);
+        o_hitrec rec;
+        memset(&rec, 0, sizeof rec);
+        int idx = -1;
+        int flag = bvh_node_hit(bvh, 0, &r, 0.001f, FLT_MAX, &rec, &idx);
+        hit[i] = flag;
+        t_out[i] = rec.t;
+        index_out[i] = flag ? idx : -1;
+        for (int c = 0; c < 3; c++) { normal_out[3 * i + c] = rec.normal.e[c]; p_out[3 * i + c] = rec.p.e[c]; }
+    }
+    return 0;
+}
+
+/* AABB::hit (aabb.h:30-43) on n (box, ray, t_min, t_max) rows */
+int o_aabb_hit_many(long long n, const float *bmin, const float *bmax, const float *origin, const float *direction,
+                    const float *t_min, const float *t_max, int *out) {
+    for (long long i = 0; i < n; i++) {
+        o_aabb box;
+        box._min = v3(bmin[3 * i], bmin[3 * i + 1], bmin[3 * i + 2]);
+        box._max = v3(bmax[3 * i], bmax[3 * i + 1], bmax[3 * i + 2]);
+        o_ray r = make_ray(v3(origin[3 * i], origin[3 * i + 1], origin[3 * i + 2]),
+                           v3(direction[3 * i], direction[3 * i + 1], direction[3 * i + 2]), 0.0f);
+        out[i] = aabb_hit(&box, &r, t_min[i], t_max[i]);
+    }
+    return 0;
+}
+
+/* op 0: surrounding_box(a, b) (aabb.h:58-66); op 1: Transform(position = b.min, rotation = b.max, scale 1).TransformAABB(a)
+ * (transform.h:22-31) */
+int o_aabb_op_many(int op, long long n, const float *amin, const float *amax, const float *bmin, const float *bmax,
+                   float *omin, float *omax) {
+    if (op < 0 || op > 1) return -1;
+    for (long long i = 0; i < n; i++) {
+        o_aabb a, o;
+        a._min = v3(amin[3 * i], amin[3 * i + 1], amin[3 * i + 2]);
+        a._max = v3(amax[3 * i], amax[3 * i + 1], amax[3 * i + 2]);
+        o_vec3 p = v3(bmin[3 * i], bmin[3 * i + 1], bmin[3 * i + 2]), q = v3(bmax[3 * i], bmax[3 * i + 1], bmax[3 * i + 2]);
+        if (op == 0) {
+            o_aabb b; b._min = p; b._max = q;
+            o = surrounding_box(a, b);
+        } else {
+            o_transform tr; tr.position = p; tr.rotation = q; tr.scale = v1(1);
+            o = a;
+            TransformAABB(&tr, &o);
+        }
+        for (int c = 0; c < 3; c++) { omin[3 * i + c] = o._min.e[c]; omax[3 * i + c] = o._max.e[c]; }
+    }
+    return 0;
+}
+
+/* which 0: every triangle's GetBV (hitable.h:45-50 = Triangle::bounding_box + TransformAABB), n_tris x 3 + n_tris x 3;
+ * which 1: the world list's GetBV (HitableList::bounding_box, hitable_list.h:94-118, + the list's TransformAABB), 3 + 3.
+ * Returns the flag bounding_box gives (which 1: false for an empty list). */
+int o_world_bounding_boxes(const o_world *w, int which, float *omin, float *omax) {
+    if (which == 0) {
+        for (int i = 0; i < w->list_size; i++) {
+            o_aabb box;
+            triangle_GetBV(&w->list[i], &box);
+            for (int c = 0; c < 3; c++) { omin[3 * i + c] = box._min.e[c]; omax[3 * i + c] = box._max.e[c]; }
+        }
+        return 1;
+    }
+    if (w->list_size < 1) return 0;                                       /* hitable_list.h:97 */
+    o_aabb box, tmp_box;
+    triangle_GetBV(&w->list[0], &tmp_box);                                /* :100 (a Triangle's bounding_box is always true) */
+    box = tmp_box;
+    for (int i = 1; i < w->list_size; i++) {                              /* :109-116 */
+        triangle_GetBV(&w->list[i], &tmp_box);
+        box = surrounding_box(box, tmp_box);
+    }
+    TransformAABB(&w->transform, &box);                                   /* GetBV, hitable.h:48 */
+    for (int c = 0; c < 3; c++) { omin[c] = box._min.e[c]; omax[c] = box._max.e[c]; }
+    return 1;
 }
 
 /* ------------------------------------------------------------------ material/material.h */

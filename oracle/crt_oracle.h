@@ -176,9 +176,33 @@ void o_render_window_ex(float *colorBuffer, const o_world *world, const o_bvh *b
 int o_world_hit(const o_world *world, const float origin[3], const float direction[3],
                 float *t_out, int *index_out, float normal_out[3]);
 
+/* Batch forms of the two above plus rec.p, and the box arithmetic of core/aabb.h / hitable/transform.h, for
+ * tests/test_ref_hit.py (which holds them to the reference's own headers running on the GPU, oracle/ref_hit.hip).
+ * o_world_hit_many: `levels` extra one-element HitableList wrappers around the world list (each one more
+ * Hitable::hit level, hitable/hitable.h:29-38). */
+int o_world_hit_many(const o_world *world, int levels, long long n, const float *origin, const float *direction,
+                     int *hit, float *t_out, int *index_out, float *normal_out, float *p_out);
+int o_bvh_hit_many(const o_bvh *bvh, long long n, const float *origin, const float *direction,
+                   int *hit, float *t_out, int *index_out, float *normal_out, float *p_out);
+/* AABB::hit (core/aabb.h:30-43) */
+int o_aabb_hit_many(long long n, const float *bmin, const float *bmax, const float *origin, const float *direction,
+                    const float *t_min, const float *t_max, int *out);
+/* op 0 surrounding_box(a, b) (aabb.h:58-66); op 1 Transform(position b.min, rotation b.max, scale 1).TransformAABB(a)
+ * (transform.h:22-31) */
+int o_aabb_op_many(int op, long long n, const float *amin, const float *amax, const float *bmin, const float *bmax,
+                   float *omin, float *omax);
+/* which 0: GetBV of every triangle; 1: GetBV of the world list (hitable_list.h:94-118).  Returns bounding_box's flag. */
+int o_world_bounding_boxes(const o_world *world, int which, float *omin, float *omax);
+
 /* ---- WritePng's pixel conversion (core/render.h:135-146): RGBA8, vertical flip,
  * char(255.99*c). rgba: nx*ny*4 bytes. */
 void o_to_rgba8(const float *colorBuffer, int nx, int ny, unsigned char *rgba);
+
+/* ---- thrust::sort(l, l + n, BoxCompare(axis)) as BVHNode's constructor calls it inside one device thread
+ * (hitable/bvh.h:84-92): Thrust's sequential stable merge sort (insertion sort per 32 elements, pairwise merges) with
+ * the comparator `val1 - val2 < 0.0 ? false : true` (bvh.h:36-41) on key[order[i]]; order is permuted in place.
+ * Pinned against rocThrust's real thrust::sort (oracle/ref_thrust_sort.hip, tests/test_ref_thrust.py). */
+int o_thrust_sort(int n, const float *key, int *order);
 
 /* ---- one core/vec3.h operation at a time (op codes of oracle/ref_vec3.cpp); pinned against the reference's own
  * vec3.h by tests/test_vec3_ref.py.  Returns 1 for an operation the oracle does not restate. */

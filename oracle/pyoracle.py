@@ -92,6 +92,16 @@ def lib():
         L.o_world_set_materials.restype = C.c_int
         L.o_render_window_ex.argtypes = [fp, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Camera), C.c_void_p] + [C.c_int] * 9
         L.o_render_window_bvh.argtypes = [fp, C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_int] * 9
+        ip = C.POINTER(C.c_int)
+        L.o_thrust_sort.argtypes = [C.c_int, fp, ip]
+        L.o_thrust_sort.restype = C.c_int
+        L.o_world_hit_many.argtypes = [C.c_void_p, C.c_int, C.c_longlong, fp, fp, ip, fp, ip, fp, fp]
+        L.o_bvh_hit_many.argtypes = [C.c_void_p, C.c_longlong, fp, fp, ip, fp, ip, fp, fp]
+        L.o_aabb_hit_many.argtypes = [C.c_longlong, fp, fp, fp, fp, fp, fp, ip]
+        L.o_aabb_op_many.argtypes = [C.c_int, C.c_longlong, fp, fp, fp, fp, fp, fp]
+        L.o_aabb_op_many.restype = C.c_int
+        L.o_world_bounding_boxes.argtypes = [C.c_void_p, C.c_int, fp, fp]
+        L.o_world_bounding_boxes.restype = C.c_int
         _lib = L
     return _lib
 
@@ -304,3 +314,65 @@ def vec3_op(op, a, b, s):
     out = np.zeros_like(a)
     rc = lib().o_vec3_op(int(op), len(a), _fp(a), _fp(b), _fp(s), _fp(out))
     return out if rc == 0 else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _rays(origin, direction):
+    d = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+    o = np.ascontiguousarray(np.broadcast_to(np.asarray(origin, dtype=np.float32).reshape(-1, 3), d.shape), dtype=np.float32)
+    return o, d
+
+
+def _hit_outputs(n):
+    return (np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros((n, 3), np.float32),
+            np.zeros((n, 3), np.float32))
+
+
+def world_hit_many(world, origin, direction, levels=0):
+    """(*world)->hit(r, 0.001, FLT_MAX, rec) for many rays (core/render.h:75); `levels` extra Hitable::hit wrappers.
+    Returns hit, t, index, normal, p."""
+    o, d = _rays(origin, direction)
+    h, t, i, nrm, p = _hit_outputs(len(d))
+    lib().o_world_hit_many(world.handle, int(levels), len(d), _fp(o), _fp(d), _ip(h), _fp(t), _ip(i), _fp(nrm), _fp(p))
+    return h, t, i, nrm, p
+
+
+def bvh_hit_many(bvh, origin, direction):
+    o, d = _rays(origin, direction)
+    h, t, i, nrm, p = _hit_outputs(len(d))
+    lib().o_bvh_hit_many(bvh.handle, len(d), _fp(o), _fp(d), _ip(h), _fp(t), _ip(i), _fp(nrm), _fp(p))
+    return h, t, i, nrm, p
+
+
+def aabb_hit_many(bmin, bmax, origin, direction, t_min, t_max):
+    a = [np.ascontiguousarray(x, dtype=np.float32) for x in (bmin, bmax, origin, direction, t_min, t_max)]
+    out = np.zeros(len(a[4]), np.int32)
+    lib().o_aabb_hit_many(len(out), *[_fp(x) for x in a], _ip(out))
+    return out
+
+
+def aabb_op_many(op, amin, amax, bmin, bmax):
+    a = [np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3) for x in (amin, amax, bmin, bmax)]
+    omin, omax = np.zeros_like(a[0]), np.zeros_like(a[0])
+    if lib().o_aabb_op_many(int(op), len(omin), *[_fp(x) for x in a], _fp(omin), _fp(omax)) != 0:
+        raise ValueError("o_aabb_op_many: bad op")
+    return omin, omax
+
+
+def world_bounding_boxes(world, which):
+    n = world.n_tris if which == 0 else 1
+    omin, omax = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    flag = lib().o_world_bounding_boxes(world.handle, int(which), _fp(omin), _fp(omax))
+    return flag, omin, omax
+
+
+def thrust_sort(key, order=None):
+    """The oracle's restatement of thrust::sort's sequential backend with BoxCompare's rule (hitable/bvh.h:9-45,86-92)."""
+    key = np.ascontiguousarray(key, dtype=np.float32)
+    order = np.arange(len(key), dtype=np.int32) if order is None else np.ascontiguousarray(order, dtype=np.int32).copy()
+    if lib().o_thrust_sort(len(order), _fp(key), _ip(order)) != 0:
+        raise MemoryError("o_thrust_sort")
+    return order

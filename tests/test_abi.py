@@ -1,4 +1,4 @@
-"""CPU tests of the C-ABI library: it loads, exports every symbol include/crt.h declares,
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/crt.h and include/crt_debug.h declare,
 its host-only entry points (camera, OBJ parse, RGBA8/PNG) agree with the oracle, and its
 compute entry points fail loudly — not silently fall back — without a HIP device."""
 import ctypes as C
@@ -15,10 +15,24 @@ from cudaraytracer_amd import _lib, api, scenes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "crt.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(crt_[a-z0-9_]+)\s*\(", text)))
+def declared_functions(headers=("crt.h", "crt_debug.h")):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(crt_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_drop_in_header_holds_no_diagnostics():
+    """include/crt.h is the surface SURVEY §8b lists plus the f-row entry points; switches, counters, self-checks and
+    timing hooks live in include/crt_debug.h."""
+    drop_in = declared_functions(("crt.h",))
+    for required in ("crt_scene_from_mesh", "crt_scene_from_obj", "crt_camera_make", "crt_render", "crt_write_png",
+                     "crt_last_error", "crt_render_rows", "crt_gather_strips", "crt_scene_build_bvh", "crt_render_rows_ex"):
+        assert required in drop_in
+    assert not [n for n in drop_in if n.startswith("crt_debug_") or n.startswith("crt_set_kernel") or n.startswith("crt_last_kernel")]
+    assert [n for n in declared_functions(("crt_debug.h",)) if n.startswith("crt_debug_")]
 
 
 def test_library_exports_every_declared_symbol(crt_built):
