@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--keep-timing-events", action="store_true", help=argparse.SUPPRESS)   # A/B: the per-frame HIP events stay on in the timed region
     ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)   # profiling: only launches of the timed frame
+    ap.add_argument("--gather", choices=("c", "torch"), default="c", help=argparse.SUPPRESS)   # N > 1: the C ABI's exchange (crt_gather_strips over an ncclComm_t
+                                                                                             # made with crt_comm_*) or torch.distributed.gather (fallback)
+    ap.add_argument("--clock-warm-s", type=float, default=0.3, help=argparse.SUPPRESS)        # untimed frames before the timed passes (clock ramp)
     args = ap.parse_args()
 
     import torch
@@ -204,7 +207,11 @@ def main():
     scene = api.Scene.from_obj(obj_path, scale=1.0)
     camera = api.init_camera(NX, NY)                       # the reference's live camera
     n_tris = scene.n_triangles
-    br = BandRenderer(scene, camera, NX, NY, rank, world, seed=0)
+    # N > 1 over RCCL: the exchange step is the C ABI's (crt_gather_strips: one grouped ncclSend/ncclRecv + the reassembly
+    # kernel) on a communicator made through the C ABI as well (crt_comm_unique_id on rank 0, broadcast over the process
+    # group that torchrun set up, crt_comm_init_rank everywhere); gloo rehearsals and --gather torch use dist.gather.
+    gather = "c" if (world > 1 and not share and args.gather == "c") else "torch"
+    br = BandRenderer(scene, camera, NX, NY, rank, world, seed=0, gather=gather)
     stream = torch.cuda.current_stream()
 
     def step():
@@ -219,14 +226,29 @@ def main():
 
     if not args.keep_timing_events:
         _lib.lib().crt_set_kernel_timing(0)                # no one reads kernel times of the timed frames: no event markers between their kernels
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()                                             # enqueue only: no host synchronisation inside the timed region
-    fence()
-    elapsed = time.perf_counter() - t0
+    # Clock ramp: a fresh box needs a few hundred milliseconds of work before the shader clock settles, and the timed
+    # region is 15-40 ms.  Untimed frames for >= clock_warm_s first (reported as clock_warm_ms; `warmup` stays what the
+    # contract says: W untimed steps right before the timed ones).
+    t_w = time.perf_counter()
+    warm_frames = 0
+    while time.perf_counter() - t_w < args.clock_warm_s:
+        for _ in range(20):
+            step()
+        fence()
+        warm_frames += 20
+    clock_warm_ms = (time.perf_counter() - t_w) * 1e3
+    # The K steps are timed THREE times (each pass: W warm-up steps, fence, exactly K steps, fence); ms_per_step is the
+    # median pass, all three are reported.
+    passes = []
+    for _ in range(3):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()                                         # enqueue only: no host synchronisation inside the timed region
+        fence()
+        passes.append(time.perf_counter() - t0)
     _lib.lib().crt_set_kernel_timing(1)
 
     # per-kernel durations (HIP events on the launch stream; reading them synchronises, so these
@@ -236,10 +258,11 @@ def main():
         br.render(args.spp, stream=stream)
         kernel_ms.append(api.last_kernel_times())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (world > 1 and share) else "cuda")
+    t = torch.tensor(passes, dtype=torch.float64, device="cpu" if (world > 1 and share) else "cuda")
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per pass: the slowest rank
+    passes = [float(x) for x in t.tolist()]
+    elapsed = float(np.median(passes))
 
     # survivor statistics of this rank's rows (one extra, untimed frame of the same shape, so
     # that every launch a profiler sees is alike): they define the algorithmic bytes of the
@@ -321,8 +344,9 @@ def main():
         torch.cuda.synchronize()
         ms_b = (time.perf_counter() - t1) / 10 * 1e3
         bvh_world = {"what": "same frame, world = BVHNode tree (crt_render_rows_bvh): tiled kernels + chain of boxes per winner",
-                     "parity": "PARITY UNPINNED: checked against the in-repo oracle only; the tree's shape rests on a reading of "
-                               "thrust::sort's sequential merge sort under a non-strict comparator (hitable/bvh.h:9-45,86-92)",
+                     "parity": "tree shape pinned against rocThrust's thrust::sort run inside one device thread; AABB::hit, box arithmetic and "
+                               "the triangle test pinned against the reference's own headers on this GPU (tests/test_ref_thrust.py, "
+                               "tests/test_ref_hit.py); BVHNode's merge rule and the render loop: in-repo oracle only (UNPINNED)",
                      "ms_per_frame": ms_b, "Mrays/s": NX * NY * args.spp / ms_b / 1e3, "host_build_s": build_s}
 
     # the recursive `shade` (core/render.h:48-67) with Lambertian / Metal / Dielectric / DiffuseLight dealt over
@@ -351,6 +375,42 @@ def main():
                     "parity": "PARITY UNPINNED (in-repo oracle; pow(x, 5.0f) and the tree's shape by stated rules)",
                     "ms_per_frame": ms_f, "M primary rays/s": NX * NY * f_spp / ms_f / 1e3}
         scene_f.close()
+
+    # The reference's OWN default workload (kernel.cu:44-51,97; render.h:191-237): 1024x512, 4 spp, max_depth 8 (dead under the
+    # live LambertShade, render.h:120), world = the BVHNode tree, frames 0..30, every frame: pose update, Update_BVH (refit),
+    # render + synchronise + copy back — through the same calls crt_driver makes (api.renderBVH mirrors kernel.cu:24-39), with
+    # the rows of the reference's timing table (frame, rendering, update, build; Loader/CSVWriter.h).  The reference's mesh
+    # (low_walking.fbx) needs the FBX SDK: the bench mesh stands in, its pose breathing by +-2 % over the 31 frames.
+    reference_default = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        rnx, rny, rspp, rdepth, f0, f1 = 1024, 512, 4, 8, 0, 30
+        pts, idx = api.parse_obj(obj_path)
+        scene_r = api.Scene.from_mesh(pts, idx, None, 1)
+        cam_r = api.init_camera(rnx, rny)
+        st_r = api.SetCurandState(rnx, rny, 0)
+        poses = {f: (pts * np.float32(1.0 + 0.02 * np.sin(2.0 * np.pi * f / 31.0))).astype(np.float32) for f in range(f0, f1 + 1)}
+        data = [["frame", "rendering", "update", "build"]]
+        api.renderBVH(rnx, rny, rspp, rdepth, f0, f1, scene_r, cam_r, st_r, data, write_png=False, poses=poses)
+        rows = data[2:]
+        ren = np.array([float(r[1]) for r in rows])
+        upd = np.array([float(r[2]) for r in rows])
+        csv_path = os.path.join(tmpdir, "output.csv")
+        api.writeCSV(csv_path, data)
+        reference_default = {
+            "what": "the reference's default run (kernel.cu:44-51,97): %dx%d, %d spp, max_depth %d, BVH world, LambertShade, frames %d..%d, "
+                    "pose update + refit + render + sync + D2H per frame (renderBVHAnimation, render.h:191-237), %d triangles"
+                    % (rnx, rny, rspp, rdepth, f0, f1, scene_r.n_triangles),
+            "parity": "tree shape and hit path pinned against rocThrust's thrust::sort and the reference's own headers "
+                      "(tests/test_ref_thrust.py, tests/test_ref_hit.py); render loop / RNG: in-repo oracle (PARITY UNPINNED)",
+            "frames": len(rows), "build_s": float(data[1][3]),
+            "rendering_ms_mean": float(ren.mean() * 1e3), "rendering_ms_median": float(np.median(ren) * 1e3),
+            "rendering_ms_first": float(ren[0] * 1e3),
+            "update_ms_mean": float(upd.mean() * 1e3), "update_ms_median": float(np.median(upd) * 1e3),
+            "Mrays/s_per_frame_median": rnx * rny * rspp / float(np.median(ren)) / 1e6,
+            "csv_bytes": os.path.getsize(csv_path),
+            "note": "host wall clock per frame as the reference's StopWatch brackets it: 'rendering' includes the synchronise and the "
+                    "6.3 MB device-to-host copy of the frame, 'update' the refit and its synchronise"}
+        scene_r.close()
 
     # The one-call surface crt_render(width, height, samples, list, camera) -> HOST RGB buffer: states restored from
     # the seed, the frame, 24.9 MB over PCIe into a pageable buffer.  Reported beside the resident figure, never as it.
@@ -394,7 +454,7 @@ def main():
         # committed rocprofv3 PMC passes of this very command (tools/profile_bench.sh; the summary
         # names the commit it was taken at).  The kernel time they are divided by IS this run's.
         traffic, traffic_src, valu = None, None, None
-        for prof in ("r3_tiled", "r2_tiled", "r1_tiled"):
+        for prof in ("r4_tiled", "r3_tiled", "r2_tiled", "r1_tiled"):
             pmc = os.path.join(ROOT, "profiles", prof, "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin_walk"))
             if os.path.exists(pmc):
                 break
@@ -403,27 +463,35 @@ def main():
                 summary = json.load(open(pmc))
                 traffic = summary["derived"]["hbm_traffic_bytes_corrected"]
                 traffic_src = "prior rocprofv3 --pmc pass of this command: %s" % os.path.relpath(pmc, ROOT)
-                # what actually bounds the kernel: VALU issue.  SQ_INSTS_VALU per launch over this run's
-                # kernel time; peak = 1 wave64 VALU instruction per 2.25 cycles per SIMD, measured on
-                # this chip for VGPR-only v_mul/v_add (profiles/r1_ubench_valu2.txt)
-                insts = summary["per_launch_counters"].get("SQ_INSTS_VALU")
-                if insts:
-                    # the clock the chip ran this kernel at in the PMC pass (same pass: cycles and duration), not the 2.4 GHz
-                    # nominal figure; summaries without it (round 2's) fall back to nominal and say so
-                    ghz = summary["derived"].get("effective_clock_GHz")
-                    clock_src = summary["derived"].get("effective_clock_source")
-                    if not ghz or "same PMC pass" not in (clock_src or ""):
-                        ghz, clock_src = 2.4, "nominal 2.4 GHz (no same-pass clock in the committed summary)"
-                    rate = insts / (k_ms * 1e-3) / 1024 / (ghz * 1e9)
-                    valu = {"unit": "wave64 VALU instructions per clock per SIMD", "achieved": rate,
-                            "peak": 1 / 2.25, "frac": rate * 2.25, "insts_per_launch": insts,
-                            "clock_GHz": ghz, "clock_source": clock_src, "source": traffic_src}
+                # What actually bounds the kernel: the VALU.  Every figure below comes from ONE source, the committed SQ pass:
+                # its instruction count, ITS kernel duration (counter passes run the kernel 20-45 % slower than the trace
+                # pass) and the clock of the same pass — nothing of this run is mixed in (round 3 divided the pass's
+                # instructions by this run's time).  issue: wave64 VALU instructions per clock per SIMD against the 2.25-cycle
+                # rate of VGPR-only v_mul/v_add measured on this chip (profiles/r1_ubench_valu2.txt); pipe_busy: the share of
+                # the pass's cycles the VALU pipe was occupied (SQ_ACTIVE_INST_VALU counts quad-cycles) — the saturation
+                # measure, since the kernel's mix is dominated by 4-cycle forms; lanes_active: SQ_THREAD_CYCLES_VALU /
+                # SQ_ACTIVE_INST_VALU where the pass collected it.
+                pl, dv = summary["per_launch_counters"], summary["derived"]
+                insts, sq_s = pl.get("SQ_INSTS_VALU"), summary.get("pmc_pass_avg_seconds", {}).get("pmc_sq")
+                ghz = dv.get("effective_clock_GHz")
+                if insts and sq_s and ghz:
+                    cycles = ghz * 1e9 * sq_s
+                    rate = insts / 1024 / cycles
+                    valu = {"unit": "wave64 VALU instructions per clock per SIMD", "achieved": rate, "peak": 1 / 2.25, "frac": rate * 2.25,
+                            "pipe_busy_frac": (pl["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cycles) if pl.get("SQ_ACTIVE_INST_VALU") else None,
+                            "lanes_active_of_64": dv.get("valu_lanes_active_of_64"),
+                            "mix_bound_frac": dv.get("valu_mix_bound_frac"),
+                            "insts_per_launch": insts, "clock_GHz": ghz, "clock_source": dv.get("effective_clock_source"),
+                            "pass_kernel_ms": sq_s * 1e3, "this_run_kernel_ms": k_ms,
+                            "source": "all from the committed SQ counter pass (its instructions, its duration, its clock): %s" % os.path.relpath(pmc, ROOT)}
             except Exception:
                 traffic = None
         out = {
             "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_runs": [x / args.steps * 1e3 for x in passes],
+            "clock_warm_ms": clock_warm_ms, "clock_warm_frames": warm_frames,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %dx%d, %d spp, %d-triangle synthetic OBJ mesh "
@@ -431,7 +499,10 @@ def main():
                                    "triangle list (HitableList path), reference camera" % (NX, NY, args.spp, n_tris),
                        "nx": NX, "ny": NY, "spp": args.spp, "triangles": n_tris,
                        "parallelism": ("1 GPU, one launch" if world == 1 else
-                                       "32-row strips dealt round-robin x%d + 1 gather to rank 0 + reassembly kernel" % world),
+                                       "32-row strips dealt round-robin x%d + %s + reassembly kernel"
+                                       % (world, "crt_gather_strips (C ABI: one grouped RCCL send/recv to rank 0 on a crt_comm_* communicator)"
+                                          if gather == "c" else "torch.distributed.gather to rank 0")),
+                       "gather_path": gather if world > 1 else None,
                        "kernel_variant": args.variant},
             # rays x triangles: what the reference's list walk would test, NOT what the tiled kernels
             # execute (they test `tile_survivors_sum` list entries per sample and tile)
@@ -450,6 +521,7 @@ def main():
             "second_workload": second,
             "bvh_world": bvh_world,
             "f2_shade": f2_shade,
+            "reference_default": reference_default,
             "pcie_inclusive_one_call": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -462,6 +534,7 @@ def main():
             out["parity_crop_hit_pixels"] = int(((ref[..., 0] - ref[..., 2]) > 0.05).sum())
         print(json.dumps(out), flush=True)
 
+    br.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

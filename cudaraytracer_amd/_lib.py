@@ -104,6 +104,12 @@ PROTOTYPES = {
     "crt_gather_strips": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "crt_debug_inject_send_failure": (C.c_int, [C.c_int]),
+    "crt_render_strips_ex": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "crt_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "crt_comm_init_rank": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "crt_comm_destroy": (C.c_int, [C.c_void_p]),
+    "crt_multi_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(CrtMaterial), C.c_int, C.POINTER(C.c_int)]),
     "crt_multi_create": (C.c_void_p, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_uint64, C.c_int]),
     "crt_multi_render": (C.c_int, [C.c_void_p, C.POINTER(CrtCamera), C.c_int, C.c_int, C.c_int, _fp]),
     "crt_multi_update_pose": (C.c_int, [C.c_void_p, _fp, C.c_int]),

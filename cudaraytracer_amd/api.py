@@ -255,6 +255,43 @@ def render_strips(scene, camera, curand_state, nx, ny, samples, first_strip, str
                                        C.c_void_p(ptr), C.c_void_p(sptr)))
 
 
+def render_strips_ex(scene, camera, curand_state, nx, ny, samples, first_strip, strip_rows_, strip_step, d_rgb,
+                     world=WORLD_LIST, shader=SHADER_LAMBERT, max_depth=8, frame_index=0, stream=None):
+    """crt_render_strips_ex: a strip set with an explicit world and shader (what a rank of a split calls)."""
+    ptr = d_rgb if isinstance(d_rgb, int) else d_rgb.data_ptr()
+    sptr = None
+    if stream is not None:
+        sptr = stream if isinstance(stream, int) else stream.cuda_stream
+    check(_lib.lib().crt_render_strips_ex(scene.handle, C.byref(camera.c), curand_state.handle, nx, ny, samples, max_depth,
+                                          frame_index, first_strip, strip_rows_, strip_step, int(world), int(shader),
+                                          C.c_void_p(ptr), C.c_void_p(sptr)))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """crt_comm_unique_id: the 128 bytes rank 0 hands to every rank (ncclGetUniqueId)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    check(_lib.lib().crt_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init_rank(world, id_bytes, rank):
+    """crt_comm_init_rank (ncclCommInitRank; collective over the `world` ranks): the ncclComm_t as an int."""
+    if len(id_bytes) != COMM_ID_BYTES:
+        raise CrtError(_lib.CRT_ERR_INVALID, "the communicator id is %d bytes" % COMM_ID_BYTES)
+    buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(id_bytes)
+    comm = C.c_void_p()
+    check(_lib.lib().crt_comm_init_rank(int(world), buf, int(rank), C.byref(comm)))
+    return comm.value
+
+
+def comm_destroy(comm):
+    if comm:
+        check(_lib.lib().crt_comm_destroy(C.c_void_p(comm)))
+
+
 def strip_part_stride(nx, ny, strip_rows_, world):
     return _lib.lib().crt_strip_part_stride(nx, ny, strip_rows_, world)
 
@@ -302,6 +339,20 @@ class MultiRenderer:
         out = np.zeros((self.ny, self.nx, 3), dtype=np.float32)
         check(_lib.lib().crt_multi_render(self.handle, C.byref(camera.c), samples, max_depth, frame_index, _fp(out)))
         return out
+
+    def configure(self, world=WORLD_LIST, shader=SHADER_LAMBERT, table=None, triangle_material=None):
+        """crt_multi_configure: the world (BVH: built once per replica, identical trees) and shader of later frames."""
+        arr, of = None, None
+        if table is not None:
+            arr = (CrtMaterial * len(table))()
+            for k, (kind, albedo, param) in enumerate(table):
+                arr[k].kind = int(kind)
+                arr[k].albedo = (C.c_float * 3)(*[float(x) for x in albedo])
+                arr[k].param = float(param)
+            if triangle_material is not None:
+                tm = np.ascontiguousarray(triangle_material, dtype=np.int32)
+                of = tm.ctypes.data_as(C.POINTER(C.c_int))
+        check(_lib.lib().crt_multi_configure(self.handle, int(world), int(shader), arr, 0 if table is None else len(table), of))
 
     def update_pose(self, new_points):
         pts = np.ascontiguousarray(new_points, dtype=np.float32).reshape(-1, 3)

@@ -808,6 +808,23 @@ int crt_render_rows_ex(const crt_scene* scene, const crt_camera* camera, crt_rng
     return render_impl(scene, camera, rng, nx, ny, samples, row_begin, row_count, 32, 1, d_rgb, stream_, world, shader, max_depth);
 }
 
+int crt_render_strips_ex(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, int nx, int ny,
+                         int samples, int max_depth, int frame_index, int first_strip, int strip_rows, int strip_step,
+                         int world, int shader, float* d_rgb, void* stream_) {
+    (void)frame_index;
+    if (nx <= 0 || ny <= 0 || samples < 0 || first_strip < 0 || strip_rows <= 0 || strip_step <= 0 ||
+        (strip_step > 1 && strip_rows % 32 != 0) || (long long)first_strip * strip_rows >= ny)
+        return fail(CRT_ERR_INVALID, "crt_render_strips_ex: bad strip layout (first %d, rows %d, step %d, ny %d)",
+                    first_strip, strip_rows, strip_step, ny);
+    if ((world != CRT_WORLD_LIST && world != CRT_WORLD_BVH) || shader < CRT_SHADER_LAMBERT || shader > CRT_SHADER_NORMAL)
+        return fail(CRT_ERR_INVALID, "crt_render_strips_ex: world %d / shader %d", world, shader);
+    if (shader == CRT_SHADER_SHADE && (max_depth < 0 || max_depth > crt::kMaxShadeDepth))
+        return fail(CRT_ERR_UNSUPPORTED, "crt_render_strips_ex: max_depth %d (0..%d)", max_depth, crt::kMaxShadeDepth);
+    const int row_begin = first_strip * strip_rows;
+    return render_impl(scene, camera, rng, nx, ny, samples, row_begin, strip_row_count(ny, row_begin, strip_rows, strip_step),
+                       strip_rows, strip_step, d_rgb, stream_, world, shader, max_depth);
+}
+
 int crt_scene_set_materials(crt_scene* s, const crt_material* table, int n_materials, const int* triangle_material) {
     if (!s || !table || n_materials < 1) return fail(CRT_ERR_INVALID, "crt_scene_set_materials: null or empty table");
     if (n_materials > 65536) return fail(CRT_ERR_UNSUPPORTED, "crt_scene_set_materials: %d materials (the kernels keep 16-bit material indices)", n_materials);

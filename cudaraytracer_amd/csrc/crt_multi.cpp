@@ -21,6 +21,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <string.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -36,6 +38,8 @@ namespace {
 
 struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -57,13 +61,15 @@ const Rccl& rccl() {
         if (!h) return;
         auto sym = [&](const char* n) { return dlsym(h, n); };
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
         r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetErrorString;
+        r.ok = r.CommInitAll && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetErrorString;
     });
     return r;
 }
@@ -165,6 +171,40 @@ int crt_debug_inject_send_failure(int count) {
     return prev;
 }
 
+static_assert(sizeof(ncclUniqueId) == CRT_COMM_ID_BYTES, "CRT_COMM_ID_BYTES must be sizeof(ncclUniqueId) (rccl.h: NCCL_UNIQUE_ID_BYTES)");
+
+int crt_comm_unique_id(void* id_bytes) {
+    if (!id_bytes) return fail(CRT_ERR_INVALID, "crt_comm_unique_id: null output");
+    const Rccl& R = rccl();
+    if (!R.ok) return fail(CRT_ERR_UNSUPPORTED, "crt_comm_unique_id: RCCL (librccl.so.1) cannot be loaded");
+    ncclUniqueId id;
+    NCCL_TRY(R.GetUniqueId(&id));
+    memcpy(id_bytes, &id, sizeof id);
+    return CRT_OK;
+}
+
+int crt_comm_init_rank(int world, const void* id_bytes, int rank, void** nccl_comm_out) {
+    if (!id_bytes || !nccl_comm_out || world < 1 || rank < 0 || rank >= world)
+        return fail(CRT_ERR_INVALID, "crt_comm_init_rank: bad argument (world %d, rank %d)", world, rank);
+    if (crt_device_count() < 1) return fail(CRT_ERR_NO_DEVICE, "crt_comm_init_rank: no HIP device");
+    const Rccl& R = rccl();
+    if (!R.ok) return fail(CRT_ERR_UNSUPPORTED, "crt_comm_init_rank: RCCL (librccl.so.1) cannot be loaded");
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(R.CommInitRank(&comm, world, id, rank));
+    *nccl_comm_out = comm;
+    return CRT_OK;
+}
+
+int crt_comm_destroy(void* nccl_comm) {
+    if (!nccl_comm) return CRT_OK;
+    const Rccl& R = rccl();
+    if (!R.ok) return fail(CRT_ERR_UNSUPPORTED, "crt_comm_destroy: RCCL (librccl.so.1) cannot be loaded");
+    NCCL_TRY(R.CommDestroy((ncclComm_t)nccl_comm));
+    return CRT_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------- one process, n_gpus devices
@@ -190,6 +230,13 @@ struct crt_multi {
     const crt_camera* job_camera = nullptr;
     const float* job_points = nullptr;
     int job_samples = 0, job_max_depth = 0, job_frame = 0, job_n_points = 0;
+    int world = CRT_WORLD_LIST, shader = CRT_SHADER_LAMBERT;   // crt_multi_configure
+    uint64_t seed = 0;
+    // a configure job (crt_multi_configure): every worker sets its replica's materials and (BVH world) builds its tree
+    bool job_configure = false;
+    const crt_material* job_table = nullptr;
+    int job_n_materials = 0;
+    const int* job_triangle_material = nullptr;
     int job_variant = 0, job_timing = 1;   // the CALLER's crt_set_kernel_variant / crt_set_kernel_timing (per-thread settings; the workers are other threads)
     std::vector<int> job_rc;
     std::vector<std::string> job_err;
@@ -212,10 +259,19 @@ void worker_main(crt_multi* m, int g) {
         int rc = CRT_OK;
         crt_set_kernel_variant(m->job_variant);
         crt_set_kernel_timing(m->job_timing);
-        if (m->job_points) rc = crt_scene_update_pose(m->scene[g], m->job_points, m->job_n_points, m->stream[g]);
+        if (m->job_configure) {
+            if (m->job_table) rc = crt_scene_set_materials(m->scene[g], m->job_table, m->job_n_materials, m->job_triangle_material);
+            // the same private stream-0 sequence on every replica (rng = NULL): identical trees (host build, deterministic)
+            if (rc == CRT_OK && m->world == CRT_WORLD_BVH && crt_scene_bvh_node_count(m->scene[g]) < 0)
+                rc = crt_scene_build_bvh(m->scene[g], nullptr, m->seed);
+        }
+        if (m->job_points) {
+            rc = crt_scene_update_pose(m->scene[g], m->job_points, m->job_n_points, m->stream[g]);
+            if (rc == CRT_OK && m->world == CRT_WORLD_BVH) rc = crt_scene_refit_bvh(m->scene[g], m->stream[g]);   // Update_BVH, render.h:215
+        }
         if (rc == CRT_OK && m->job_camera && m->rng[g])
-            rc = crt_render_strips(m->scene[g], m->job_camera, m->rng[g], m->nx, m->ny, m->job_samples, m->job_max_depth,
-                                   m->job_frame, g, kStripRows, m->n, m->piece[g], m->stream[g]);
+            rc = crt_render_strips_ex(m->scene[g], m->job_camera, m->rng[g], m->nx, m->ny, m->job_samples, m->job_max_depth,
+                                      m->job_frame, g, kStripRows, m->n, m->world, m->shader, m->piece[g], m->stream[g]);
         m->job_rc[g] = rc;
         if (rc != CRT_OK) m->job_err[g] = crt_last_error();
         {
@@ -289,7 +345,7 @@ crt_multi* crt_multi_create(const float* points, int n_points, const float* idx3
     if (!R.ok) { fail(CRT_ERR_UNSUPPORTED, "crt_multi_create: RCCL (librccl.so.1) cannot be loaded"); return nullptr; }
     crt_multi* m = new (std::nothrow) crt_multi;
     if (!m) { fail(CRT_ERR_NOMEM, "crt_multi_create: out of memory"); return nullptr; }
-    m->n = n_gpus; m->nx = nx; m->ny = ny;
+    m->n = n_gpus; m->nx = nx; m->ny = ny; m->seed = seed;
     m->dev.resize(n_gpus);
     for (int g = 0; g < n_gpus; ++g) m->dev[g] = g;
     m->scene.assign(n_gpus, nullptr); m->rng.assign(n_gpus, nullptr); m->piece.assign(n_gpus, nullptr);
@@ -332,6 +388,23 @@ void read_caller_settings(crt_multi* m) {
     crt_set_kernel_timing(m->job_timing);
 }
 }  // namespace
+
+int crt_multi_configure(crt_multi* m, int world, int shader, const crt_material* table, int n_materials, const int* triangle_material) {
+    if (!m || (world != CRT_WORLD_LIST && world != CRT_WORLD_BVH) || shader < CRT_SHADER_LAMBERT || shader > CRT_SHADER_NORMAL ||
+        (table && n_materials < 1))
+        return fail(CRT_ERR_INVALID, "crt_multi_configure: bad argument (world %d, shader %d)", world, shader);
+    read_caller_settings(m);
+    const int prev_world = m->world, prev_shader = m->shader;
+    m->world = world; m->shader = shader;
+    m->job_camera = nullptr; m->job_points = nullptr;
+    m->job_configure = true;
+    m->job_table = table; m->job_n_materials = n_materials; m->job_triangle_material = triangle_material;
+    const int rc = run_job(m);
+    m->job_configure = false;
+    m->job_table = nullptr; m->job_triangle_material = nullptr;
+    if (rc != CRT_OK) { m->world = prev_world; m->shader = prev_shader; }
+    return rc;
+}
 
 int crt_multi_update_pose(crt_multi* m, const float* new_points, int n_points) {
     if (!m || !new_points) return fail(CRT_ERR_INVALID, "crt_multi_update_pose: null argument");

@@ -125,9 +125,18 @@ class BandRenderer:
     """Per-rank state of a split render: scene + camera + the RNG states of this rank's rows
     + its device buffer.  mode "strips" (default when world_size > 1) or "bands"."""
 
-    def __init__(self, scene, camera, nx, ny, rank, world_size, seed=0, device="cuda", mode=None):
+    def __init__(self, scene, camera, nx, ny, rank, world_size, seed=0, device="cuda", mode=None, bvh=False, gather="torch",
+                 group=None):
         from . import api
         self.api = api
+        self.bvh = bool(bvh)                 # world = the scene's BVHNode tree (crt_scene_build_bvh) instead of its list
+        # gather "c": the exchange step behind the C ABI — crt_gather_strips (one grouped ncclSend / ncclRecv to rank 0 + the
+        # reassembly kernel, csrc/crt_multi.cpp) on a communicator made with crt_comm_unique_id / crt_comm_init_rank; the 128
+        # id bytes travel from rank 0 over the process group the launcher set up.  "torch": torch.distributed.gather.
+        self.gather_path = gather if (world_size > 1 or gather == "c") else "torch"
+        self.comm = None
+        self._full = None
+        self._parts = None
         self.scene, self.camera = scene, camera
         self.nx, self.ny = nx, ny
         self.rank, self.world_size = rank, world_size
@@ -146,8 +155,36 @@ class BandRenderer:
         else:
             max_rows = partition_rows(ny, world_size, 0)[1]
         like = torch.zeros(1, dtype=torch.float32, device=device)
-        self.bufs = _GatherBuffers(max_rows * nx * 3, rank, world_size, like)
-        self.band = self.bufs.send[: self.row_count * nx * 3]
+        if self.gather_path == "c":
+            if self.mode != "strips":
+                raise ValueError("gather='c' needs the strip partition (crt_gather_strips)")
+            self.bufs = None
+            self.band = like.new_zeros(max(self.row_count, 1) * nx * 3)[: self.row_count * nx * 3]
+            self.part_stride = api.strip_part_stride(nx, ny, STRIP_ROWS, world_size)
+            if rank == 0:
+                self._parts = like.new_empty(self.part_stride * world_size)
+                self._full = like.new_empty(ny * nx * 3)
+            self.comm = self._make_comm(group, device)
+        else:
+            self.bufs = _GatherBuffers(max_rows * nx * 3, rank, world_size, like)
+            self.band = self.bufs.send[: self.row_count * nx * 3]
+
+    def _make_comm(self, group, device):
+        """rank 0: crt_comm_unique_id; everyone: the bytes by broadcast, then crt_comm_init_rank (collective)."""
+        api = self.api
+        if self.world_size == 1:
+            return api.comm_init_rank(1, api.comm_unique_id(), 0)
+        on = device if dist.get_backend(group) == "nccl" else "cpu"
+        ident = torch.zeros(api.COMM_ID_BYTES, dtype=torch.uint8, device=on)
+        if self.rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(api.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(ident, src=0, group=group)
+        return api.comm_init_rank(self.world_size, bytes(ident.cpu().numpy().tobytes()), self.rank)
+
+    def close(self):
+        if self.comm:
+            self.api.comm_destroy(self.comm)
+            self.comm = None
 
     def render(self, samples, frame_index=0, stream=None):
         """Enqueue this rank's rows (no synchronisation)."""
@@ -156,13 +193,18 @@ class BandRenderer:
             return
         if self.mode == "strips":
             self.api.render_strips(self.scene, self.camera, self.state, self.nx, self.ny, samples, self.rank,
-                                   STRIP_ROWS, self.world_size, self.band, frame_index=frame_index, stream=stream)
+                                   STRIP_ROWS, self.world_size, self.band, frame_index=frame_index, stream=stream, bvh=self.bvh)
         else:
             self.api.render_rows(self.scene, self.camera, self.state, self.nx, self.ny, samples,
                                  self.row_begin, self.row_count, self.band, frame_index=frame_index,
-                                 stream=stream)
+                                 stream=stream, bvh=self.bvh)
 
-    def gather(self, group=None):
+    def gather(self, group=None, stream=None):
+        if self.gather_path == "c":
+            stream = stream if stream is not None else torch.cuda.current_stream()
+            self.api.gather_strips(self.band if self.row_count else None, self.nx, self.ny, STRIP_ROWS, self.rank, self.world_size,
+                                   self._parts, self.part_stride, self._full, self.comm, stream=stream)
+            return self._full.view(self.ny, self.nx, 3) if self.rank == 0 else None
         if self.mode == "strips":
             return gather_strips(self.band, self.nx, self.ny, self.rank, self.world_size, STRIP_ROWS, group, self.bufs)
         return gather_framebuffer(self.band, self.nx, self.ny, self.rank, self.world_size, group, self.bufs)

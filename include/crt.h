@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 3
+#define CRT_ABI_VERSION 4
 
 enum {
     CRT_OK = 0,
@@ -277,6 +277,12 @@ int crt_render_rows_ex(const crt_scene *scene, const crt_camera *camera, crt_rng
  * context state.  crt_multi_free releases the contexts of its own streams. */
 int crt_stream_release(void *stream);
 
+/* The same on a strip set (crt_render_strips' layout): what a rank of a multi-GPU split calls for the BVH world and the
+ * other shaders. */
+int crt_render_strips_ex(const crt_scene *scene, const crt_camera *camera, crt_rng *rng, int nx, int ny,
+                         int samples, int max_depth, int frame_index, int first_strip, int strip_rows,
+                         int strip_step, int world, int shader, float *d_rgb, void *stream);
+
 /* ---- multi-GPU ------------------------------------------------------------------
  * The reference is single-GPU; this section is the north-star split: strips of
  * `strip_rows` (32) image rows dealt round-robin to `world` ranks, rendered with
@@ -306,6 +312,17 @@ int crt_gather_strips(const float *d_piece, int nx, int ny, int strip_rows, int 
                       float *d_parts, int64_t part_stride, float *d_full, void *nccl_comm,
                       void *stream);
 
+/* The communicator crt_gather_strips needs, for hosts that run one process (or thread) per GPU and have no RCCL code of
+ * their own: rank 0 calls crt_comm_unique_id and hands the CRT_COMM_ID_BYTES bytes to every rank over whatever channel
+ * the host already has (bench.py: a broadcast over the torch.distributed process group torchrun set up; an MPI_Bcast; a
+ * file), then EVERY rank calls crt_comm_init_rank with the device it renders on current (rccl.h: ncclGetUniqueId /
+ * ncclCommInitRank; collective: it returns when all `world` ranks have called it).  crt_comm_destroy before the process
+ * ends.  CRT_ERR_UNSUPPORTED when RCCL cannot be loaded. */
+#define CRT_COMM_ID_BYTES 128
+int crt_comm_unique_id(void *id_bytes);
+int crt_comm_init_rank(int world, const void *id_bytes, int rank, void **nccl_comm_out);
+int crt_comm_destroy(void *nccl_comm);
+
 /* One process, n_gpus devices (devices 0..n_gpus-1): the scene is replicated, every device gets
  * its strip set's RNG states (seed, stream = global pixel index), a stream and a host worker
  * thread; communicators come from ncclCommInitAll.  replaces: the driver shape of
@@ -326,7 +343,15 @@ crt_multi *crt_multi_create(const float *points, int n_points, const float *idx3
  * states persist from call to call like the reference's frame loop. */
 int crt_multi_render(crt_multi *m, const crt_camera *camera, int samples, int max_depth,
                      int frame_index, float *rgb_out);
-/* crt_scene_update_pose on every replica. */
+/* The reference's shipped configuration (kernel.cu:97: renderBVH) and the other shaders behind the multi-device driver:
+ * world = CRT_WORLD_LIST | CRT_WORLD_BVH, shader = CRT_SHADER_*; table / triangle_material as crt_scene_set_materials
+ * (table == NULL keeps the single Lambertian).  CRT_WORLD_BVH builds the tree once per replica from the same private
+ * stream-0 sequence (crt_scene_build_bvh(scene, NULL, seed)): the replicas hold identical trees.  Later
+ * crt_multi_render calls use this world and shader (every device: crt_render_strips_ex), crt_multi_update_pose also
+ * refits the trees.  Default after crt_multi_create: the list world with LambertShade. */
+int crt_multi_configure(crt_multi *m, int world, int shader, const crt_material *table, int n_materials,
+                        const int *triangle_material);
+/* crt_scene_update_pose on every replica (and crt_scene_refit_bvh where the world is the BVH). */
 int crt_multi_update_pose(crt_multi *m, const float *new_points, int n_points);
 /* Device pointer (device 0) of the frame assembled by the last crt_multi_render. */
 const float *crt_multi_frame(const crt_multi *m);

@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(crt_built):
         assert hasattr(crt_built, n), "libcrt_hip.so does not export %s" % n
         assert n in _lib.PROTOTYPES, "no ctypes prototype for %s" % n
     assert set(_lib.PROTOTYPES) == set(names)
-    assert crt_built.crt_abi_version() == 3
+    assert crt_built.crt_abi_version() == 4
 
 
 def test_camera_matches_oracle(crt_built, oracle):

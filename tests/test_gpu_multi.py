@@ -346,6 +346,27 @@ def test_streams_come_and_go_without_growing_device_memory(gpu, crt_built):
     free1, _ = gpu.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), "device memory shrank by %.1f MB over 100 released streams" % ((free0 - free1) / 2**20)
     assert crt_built.crt_stream_release(C.c_void_p(12345)) == 0                # nothing to release: still CRT_OK
+    # A host that destroys streams WITHOUT crt_stream_release leaves their contexts behind, and the runtime hands the
+    # handles out again.  Where the process's HIP runtime has hipStreamGetId (>= 7.1) the library notices by itself; torch's
+    # bundled 7.0 runtime does not have it, so the branch is driven through crt_debug_force_stream_recycle here: the
+    # context is reset (device synchronised, events and cached occupancy dropped), and the frame is still the frame.
+    for _ in range(4):
+        one_stream(release=False)
+    h = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(h)) == 0
+    try:
+        for forced in (0, 1, 1):
+            assert crt_built.crt_debug_force_stream_recycle(forced) == 0
+            st.reset(0)
+            api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=RawStream(h.value))   # 2nd, 3rd: look-up of the kept context
+            assert hip.hipStreamSynchronize(h) == 0
+            assert crt_built.crt_debug_force_stream_recycle(0) == 0            # the look-up consumed the forced recycle
+            assert np.array_equal(bits(d.cpu().numpy().reshape(ny, nx, 3)), bits(want))
+            assert api.last_kernel_times()[0] > 0.0                            # the reset context's fresh events work
+    finally:
+        crt_built.crt_debug_force_stream_recycle(0)
+        assert crt_built.crt_stream_release(h) == 0
+        assert hip.hipStreamDestroy(h) == 0
     def one_renderer():
         m = api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 1)
         m.render(cam, spp)
@@ -385,3 +406,122 @@ def test_one_call_render_is_repeatable_and_keeps_its_buffers(gpu, crt_built, ora
     assert np.array_equal(bits(e), bits(ref2))
     assert crt_built.crt_stream_release(None) == 0
     assert np.array_equal(bits(api.render(nx, ny, spp, scene, cam, seed=0)), bits(a))
+
+
+def test_band_renderer_c_path_gather_world_one(gpu):
+    """What bench.py --gpus N runs per rank over RCCL, at world 1: the communicator comes from the C ABI
+    (crt_comm_unique_id + crt_comm_init_rank = ncclGetUniqueId + ncclCommInitRank), the exchange step is crt_gather_strips
+    (the root's send to itself goes through RCCL), the frame equals the single-launch frame; two frames continue the
+    streams."""
+    from cudaraytracer_amd.dist import BandRenderer
+    sc = scenes.displaced_sphere(24, 30)
+    nx, ny, spp = 200, 150, 3
+    scene, cam = make(sc, nx, ny)
+    st = api.SetCurandState(nx, ny, 0)
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    wants = []
+    for _ in range(2):
+        api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=gpu.cuda.current_stream())
+        gpu.cuda.synchronize()
+        wants.append(d.cpu().numpy().reshape(ny, nx, 3).copy())
+    br = BandRenderer(scene, cam, nx, ny, 0, 1, seed=0, mode="strips", gather="c")
+    try:
+        assert br.gather_path == "c" and br.comm
+        for k in range(2):
+            br.render(spp)
+            full = br.gather()
+            gpu.cuda.synchronize()
+            assert np.array_equal(bits(full.cpu().numpy()), bits(wants[k])), k
+    finally:
+        br.close()
+    assert br.comm is None
+
+
+def test_comm_helpers_reject_bad_arguments(gpu, crt_built):
+    ident = api.comm_unique_id()
+    assert len(ident) == api.COMM_ID_BYTES and any(ident)
+    with pytest.raises(_lib.CrtError):
+        api.comm_init_rank(2, ident, 2)                 # rank out of range
+    with pytest.raises(_lib.CrtError):
+        api.comm_init_rank(1, ident[:5], 0)
+    assert crt_built.crt_comm_destroy(None) == 0
+
+
+@pytest.mark.parametrize("world_kind,shader", [(api.WORLD_BVH, api.SHADER_LAMBERT), (api.WORLD_BVH, api.SHADER_SHADE),
+                                               (api.WORLD_LIST, api.SHADER_NORMAL)])
+def test_strips_ex_reassembled_equal_rows_ex(gpu, world_kind, shader):
+    """crt_render_strips_ex: the strip sets of a 3-way split with an explicit world and shader, reassembled, equal the
+    whole frame through crt_render_rows_ex (pixels; the RNG stream of a pixel is its global index)."""
+    sc = scenes.displaced_sphere(20, 26)
+    nx, ny, spp, world = 160, 136, 3, 3
+    scene, cam = make(sc, nx, ny)
+    scene.set_materials([(api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0), (api.METAL, (0.8, 0.85, 0.88), 0.1), (api.DIELECTRIC, (1, 1, 1), 1.5),
+                         (api.DIFFUSE_LIGHT, (4.0, 4.0, 4.0), 0.0)], (np.arange(scene.n_triangles) // 60 % 4).astype(np.int32))
+    scene.build_bvh(None, 0)
+    st = api.SetCurandState(nx, ny, 0)
+    d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=world_kind, shader=shader, max_depth=6, stream=gpu.cuda.current_stream())
+    gpu.cuda.synchronize()
+    want = d.cpu().numpy().reshape(ny, nx, 3)
+    stride = api.strip_part_stride(nx, ny, 32, world)
+    parts = gpu.full((world * stride,), float("nan"), dtype=gpu.float32, device="cuda")
+    for r in range(world):
+        stt = api.CurandState.for_strips(nx, ny, r, 32, world, 0)
+        api.render_strips_ex(scene, cam, stt, nx, ny, spp, r, 32, world, parts.data_ptr() + 4 * r * stride, world=world_kind,
+                             shader=shader, max_depth=6, stream=gpu.cuda.current_stream())
+    full = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+    api.assemble_strips(parts, stride, nx, ny, 32, world, full, stream=gpu.cuda.current_stream())
+    gpu.cuda.synchronize()
+    assert np.array_equal(bits(full.cpu().numpy().reshape(ny, nx, 3)), bits(want))
+
+
+def test_single_process_driver_runs_the_shipped_configuration(gpu, oracle):
+    """crt_multi_configure(CRT_WORLD_BVH): the reference's shipped world (kernel.cu:97 renderBVH) behind the multi-device
+    driver — tree built per replica, frames equal the oracle's BVH frames, a pose update refits (Update_BVH, render.h:215);
+    then the recursive shader with materials through the same driver against crt_render_rows_ex."""
+    sc = scenes.displaced_sphere(16, 20)
+    nx, ny, spp = 96, 80, 3
+    c = sc["camera"]
+    cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+    m = api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 1)
+    try:
+        m.configure(api.WORLD_BVH, api.SHADER_LAMBERT)
+        f0 = m.render(cam, spp)
+        moved = (sc["points"] * np.float32(1.1)).astype(np.float32)
+        m.update_pose(moved)
+        f1 = m.render(cam, spp, frame_index=1)
+        w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        ocam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
+        # the driver builds its trees from a private stream-0 sequence: the frame's own stream 0 is untouched by the build
+        bvh = oracle.Bvh(w, oracle.fresh_states(nx, ny))
+        states = oracle.fresh_states(nx, ny)
+        r0, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
+        assert np.array_equal(bits(f0), bits(r0))
+        w.update_pose(moved)
+        bvh.update()
+        r1, _ = oracle.render_bvh(bvh, ocam, nx, ny, spp, states, frame=1)
+        assert np.array_equal(bits(f1).reshape(-1, 3)[1:], bits(r1).reshape(-1, 3)[1:])   # pixel 0 of frame 1: DESIGN.md §1
+        # shade with four material classes: the driver against the single-device entry point on an identical scene
+        table = [(api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0), (api.METAL, (0.8, 0.85, 0.88), 0.1), (api.DIELECTRIC, (1, 1, 1), 1.5),
+                 (api.DIFFUSE_LIGHT, (4.0, 4.0, 4.0), 0.0)]
+        n_tris = len(sc["idx"])
+        of = (np.arange(n_tris) // 40 % 4).astype(np.int32)
+        m2 = api.MultiRenderer(sc["points"], sc["idx"], sc["normals"], sc["index_base"], nx, ny, 1)
+        try:
+            m2.configure(api.WORLD_BVH, api.SHADER_SHADE, table, of)
+            g = m2.render(cam, spp, max_depth=5)
+        finally:
+            m2.close()
+        scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        scene.set_materials(table, of)
+        scene.build_bvh(None, 0)
+        st = api.SetCurandState(nx, ny, 0)
+        d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
+        api.render_rows_ex(scene, cam, st, nx, ny, spp, 0, ny, d, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=5,
+                           stream=gpu.cuda.current_stream())
+        gpu.cuda.synchronize()
+        assert np.array_equal(bits(g), bits(d.cpu().numpy().reshape(ny, nx, 3)))
+        with pytest.raises(_lib.CrtError):
+            m.configure(7, api.SHADER_LAMBERT)
+    finally:
+        m.close()

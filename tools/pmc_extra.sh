@@ -7,8 +7,8 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d "$OUT/pmc_wait" -- python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > "$OUT/bench_pmc_wait.json" 2> "$OUT/pmc_wait.err" || { tail -5 "$OUT/pmc_wait.err"; exit 1; }
-rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH --output-format csv -d "$OUT/pmc_lds" -- python3 "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > "$OUT/bench_pmc_lds.json" 2> "$OUT/pmc_lds.err" || { tail -5 "$OUT/pmc_lds.err"; exit 1; }
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d "$OUT/pmc_wait" -- python3 "$REPO/bench.py" --steps 1 --warmup 0 --clock-warm-s 0 --no-cpu-baseline --no-extras "$@" > "$OUT/bench_pmc_wait.json" 2> "$OUT/pmc_wait.err" || { tail -5 "$OUT/pmc_wait.err"; exit 1; }
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH --output-format csv -d "$OUT/pmc_lds" -- python3 "$REPO/bench.py" --steps 1 --warmup 0 --clock-warm-s 0 --no-cpu-baseline --no-extras "$@" > "$OUT/bench_pmc_lds.json" 2> "$OUT/pmc_lds.err" || { tail -5 "$OUT/pmc_lds.err"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

@@ -3,7 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/pmc_write_$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/err.txt
+timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -- python3 $REPO/bench.py --steps 1 --warmup 0 --clock-warm-s 0 --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/err.txt
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(float); n = collections.defaultdict(set)

@@ -6,8 +6,8 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/prof_wv
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/brute" -- python3 "$REPO/bench.py" --variant 1 --spp 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > "$OUT/b.json" 2> "$OUT/b.err" || { tail -5 "$OUT/b.err"; exit 1; }
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/tiled1" -- python3 "$REPO/bench.py" --spp 1 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > "$OUT/t.json" 2> "$OUT/t.err" || { tail -5 "$OUT/t.err"; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/brute" -- python3 "$REPO/bench.py" --variant 1 --spp 1 --steps 1 --warmup 0 --clock-warm-s 0 --no-cpu-baseline --no-extras > "$OUT/b.json" 2> "$OUT/b.err" || { tail -5 "$OUT/b.err"; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/tiled1" -- python3 "$REPO/bench.py" --spp 1 --steps 1 --warmup 0 --clock-warm-s 0 --no-cpu-baseline --no-extras > "$OUT/t.json" 2> "$OUT/t.err" || { tail -5 "$OUT/t.err"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

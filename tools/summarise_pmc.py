@@ -17,7 +17,7 @@ alg_bytes = float(sys.argv[4]) if len(sys.argv) > 4 else None
 ctr = {}         # kernel -> pass -> counter -> sum
 disp = {}        # (kernel, pass, counter) -> dispatch ids
 dur = {}         # (pass, kernel) -> {dispatch id: seconds}
-PASSES = ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait", "pmc_lds")
+PASSES = ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait", "pmc_lds", "pmc_lanes")
 for d in PASSES:
     for f in glob.glob("%s/%s/*/*_counter_collection.csv" % (prof, d)):
         for r in csv.DictReader(open(f)):
@@ -80,6 +80,20 @@ if sq_s and r.get("GRBM_GUI_ACTIVE"):
         t_k = float(tr["AverageNs"]) * 1e-9 if tr is not None else sq_s
         dv["valu_wave_insts_per_clk_per_simd"] = r["SQ_INSTS_VALU"] / t_k / 1024 / (dv["effective_clock_GHz"] * 1e9)
         dv["valu_issue_frac_of_2.25_cycle_peak"] = dv["valu_wave_insts_per_clk_per_simd"] * 2.25
+        # the same from ONE source — the SQ pass's own duration (counter passes perturb the kernel: 20-45 % slower)
+        dv["valu_wave_insts_per_clk_per_simd_same_pass"] = r["SQ_INSTS_VALU"] / sq_s / 1024 / (dv["effective_clock_GHz"] * 1e9)
+        dv["valu_issue_frac_same_pass"] = dv["valu_wave_insts_per_clk_per_simd_same_pass"] * 2.25
+    if r.get("SQ_ACTIVE_INST_VALU"):
+        # SQ_ACTIVE_INST_VALU counts quad-cycles the VALU pipe is occupied, summed over all SIMDs: x 4 / 1024 SIMDs = cycles
+        # per SIMD, against the cycles of the same pass.  The saturation measure of a kernel whose mix is mostly 4-cycle forms.
+        dv["valu_pipe_busy_frac"] = r["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (dv["effective_clock_GHz"] * 1e9 * sq_s)
+        if r.get("SQ_INSTS_VALU"):
+            dv["valu_cycles_per_instruction"] = r["SQ_ACTIVE_INST_VALU"] * 4 / r["SQ_INSTS_VALU"]
+lanes = per_pass[key].get("pmc_lanes", {})
+if lanes.get("SQ_THREAD_CYCLES_VALU") and lanes.get("SQ_ACTIVE_INST_VALU"):
+    # lanes active per VALU cycle (tools/pmc_lanes.sh, round 3: 64.0 for full wavefronts, 37 for the generic kernel)
+    dv["valu_lanes_active_of_64"] = lanes["SQ_THREAD_CYCLES_VALU"] / lanes["SQ_ACTIVE_INST_VALU"]
+    dv["valu_lanes_active_source"] = "SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU of the pmc_lanes pass"
 if r.get("SQ_WAVE_CYCLES"):
     wt = per_pass[key].get("pmc_wait", {})
     for c, name in (("SQ_WAIT_ANY", "wave_cycles_parked_frac"), ("SQ_WAIT_INST_ANY", "wave_cycles_waiting_to_issue_frac"),
