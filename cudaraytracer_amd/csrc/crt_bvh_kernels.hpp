@@ -483,6 +483,22 @@ __device__ __forceinline__ void bvh_trace(const BvhView& b, const float* __restr
     bvh_walk_general<FAST, PRIMARY>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot, dir_used);
 }
 
+// The hot direction chain of the tiled kernels' BVH mode, per ray: c2 = F(c1), c3 = F(c2) with c1 = rotate(unit_vector(d0), 0)
+// = d1.  For a ray whose components are all ordinary (finite, |component| >= 2^-40) rotate(., 0) is the identity bit for bit
+// (x * 1 + y * (+-0) + z * (+-0) = x for x != 0) and unit_vector_fast is the IEEE result, so the chain is three guard-free
+// normalisations; ONE test at the end covers it: |c3 components| >= 2^-39 (and finite) puts the same components of d1 and c2
+// above 2^-40 — each normalisation moves a component by a few ulp of itself, so a tiny, zero or non-finite component stays
+// what it was — and c4 == c3 says the chain has settled.  `hot` false: the caller recomputes the chain literally
+// (rot0_exact, chain_next) for that lane; c3 must not be used for it.  Rounds 2-3 ran the guarded forms: four rotate
+// guards, three range guards and a nine-component minimum per sample.
+__device__ __forceinline__ bool hot_chain(V3 d1, V3& c3) {
+    const V3 c2 = unit_vector_fast_ng(d1);
+    c3 = unit_vector_fast_ng(c2);
+    const V3 c4 = unit_vector_fast_ng(c3);
+    const float lo = fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z)), hi = fmaxf(fmaxf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z));
+    return same_bits(c4, c3) && lo >= 1.8189894035458565e-12f && hi <= 2.0f;   // 2^-39; (NaN fails both comparisons)
+}
+
 // ---- the chain of boxes for the tiled kernel's BVH mode ----------------------------------------------
 // A triangle is reached through the tree iff the boxes of its leaf and of all the leaf's ancestors
 // pass AABB::hit for this ray (each with the direction of its depth; on the hot chain c1 for the

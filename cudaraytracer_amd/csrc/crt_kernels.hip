@@ -310,6 +310,16 @@ __device__ __forceinline__ V3 unit_vector_fast(V3 v) {
     return V3{div_by_rcp(v.x, len, y), div_by_rcp(v.y, len, y), div_by_rcp(v.z, len, y)};
 }
 
+// The same WITHOUT the range guard, for callers that check the range themselves afterwards (the BVH mode's hot direction
+// chain: one test on the last element covers the whole chain, see hot_chain).  On inputs outside the guarded range the
+// result is merely not the IEEE quotient — no trap, no loop — and the caller must not use it.
+__device__ __forceinline__ V3 unit_vector_fast_ng(V3 v) {
+    const float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float len = sqrt_normal(s2);
+    const float y = reciprocal<true>(len);
+    return V3{div_by_rcp(v.x, len, y), div_by_rcp(v.y, len, y), div_by_rcp(v.z, len, y)};
+}
+
 // the y component of unit_vector(v) alone (sky-only tiles)
 __device__ __forceinline__ float unit_vector_fast_y(V3 v) {
     const float s2 = v.x * v.x + v.y * v.y + v.z * v.z;
@@ -462,6 +472,27 @@ __device__ __forceinline__ void walk_list_strided(const float* __restrict__ rec,
         const int n = min(64, j1 - base);
         const int mine = (lane < n) ? (int)lst[first + (base + lane) * step] : 0;
         walk<FAST>(rec, 0, n, [&](int k) { return __builtin_amdgcn_readlane(mine, k); }, d, closest, hit_idx);
+    }
+}
+
+// BVH mode: the entries of a slice beyond its staged ones.  The record of slot s is tested like above, but what orders ties
+// and comes back in hit_idx is the TREE's order — key = (0x3fffff - partner[s]) << 9 | tag (smaller wins = later leaf, first
+// in its leaf; tag marks the entry as unstaged: the master looks the slot up through the partner table) — with the pool
+// word's cull-sure bit on top.  Slots and keys are wave-uniform (readlane of one coalesced load / gather per 64 entries).
+template <bool FAST>
+__device__ __forceinline__ void walk_list_strided_keyed(const float* __restrict__ rec, const uint32_t* __restrict__ lst,
+                                                        const int* __restrict__ partner, unsigned tag, int first, int step, int j0, int j1,
+                                                        int lane, V3 d, float& closest, int& hit_idx) {
+    for (int base = j0; base < j1; base += 64) {
+        const int n = min(64, j1 - base);
+        const int mine = (lane < n) ? (int)lst[first + (base + lane) * step] : 0;
+        const int key = (lane < n) ? (int)(((unsigned)mine & 0x80000000u) | ((unsigned)(0x3fffff - partner[mine & 0x7fffffff]) << 9) | tag) : 0;
+        for (int k = 0; k < n; ++k) {
+            const int slot = __builtin_amdgcn_readlane(mine, k), kk = __builtin_amdgcn_readlane(key, k);
+            const Rec16 r1 = load_rec(rec, slot);
+            asm volatile("" ::"s"(r1.f[0]), "s"(r1.f[2]), "s"(r1.f[3]), "s"(r1.f[10]), "s"(r1.f[11]), "s"(r1.f[14]), "s"(r1.f[15]));
+            exact_test<FAST>(r1, kk, d, closest, hit_idx);
+        }
     }
 }
 
@@ -1258,6 +1289,7 @@ struct Cand {
 
 typedef float4 StageArea[4][64];   // one wavefront's LDS staging area: 4 planes x 64 entries x 16 B (plane-major:
                                    // per-lane reads of different entries fall into different banks)
+typedef float4 StageArea32[4][32]; // the BVH mode stages 32 entries per wavefront (its LDS also holds slots and leaf boxes; 3 blocks per CU)
 
 // q = radius * 1.0001 + K * M of one form on a 1-pixel cell (hu, hv: pixel half extents incl. position slack)
 __device__ __forceinline__ float pixel_q(float K, float hu, float hv, float B, float C, float M) {
@@ -1297,7 +1329,8 @@ __device__ __forceinline__ float pixel_forms(const RenderParams& p, float4& f0, 
 
 // lane j < n holds list entry j (`entry`, raw pool word).  Leaves the exact records of the n
 // entries in `area` and the lane's candidate masks in `cand`.
-__device__ __forceinline__ void stage_candidates(StageArea& area, float* qw, int* ent, const RenderParams& p,
+template <int CAP = 64, class Area>   // CAP: entries the area holds (n <= CAP); CAP <= 32: only the low mask words are used
+__device__ __forceinline__ void stage_candidates(Area& area, float* qw, int* ent, const RenderParams& p,
                                                  const float4* __restrict__ cls, int n_pad,
                                                  const float* __restrict__ rec, int entry, int n, int lane,
                                                  int x, int y_global, Cand& cand) {
@@ -1316,8 +1349,8 @@ __device__ __forceinline__ void stage_candidates(StageArea& area, float* qw, int
         bool sure_b;
         const unsigned may = pixel_may_hit(p, area[0][k], area[1][k], area[2][k], area[3][k], qw[k], x, y_global, sure_b) ? 1u : 0u;   // broadcast reads
         const unsigned sure = sure_b ? 1u : 0u;
-        if (k < 32) { cand.lo |= may << k; cand.sure_lo |= sure << k; }
-        else        { cand.hi |= may << (k - 32); cand.sure_hi |= sure << (k - 32); }
+        if (CAP <= 32 || k < 32) { cand.lo |= may << (k & 31); cand.sure_lo |= sure << (k & 31); }
+        else                     { cand.hi |= may << (k - 32); cand.sure_hi |= sure << (k - 32); }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < n) {   // now the exact records, same slots, and the pool words (lanes may be switched off later)
@@ -1368,10 +1401,11 @@ __device__ __forceinline__ void exact_test_lane(const RecV& rc, int i, bool sure
 }
 
 // one sample of one lane against its candidates
-__device__ __forceinline__ void trace_candidates(StageArea& area, const int* ent, const Cand& cand, V3 d2,
+template <int CAP = 64, class Area>
+__device__ __forceinline__ void trace_candidates(Area& area, const int* ent, const Cand& cand, V3 d2,
                                                  float& closest, int& hit_idx) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < (CAP > 32 ? 2 : 1); ++half) {
         unsigned m = half ? cand.hi : cand.lo;
         const unsigned sm = half ? cand.sure_hi : cand.sure_lo;
         while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
@@ -1430,8 +1464,9 @@ __device__ __forceinline__ bool hit_inside_leaf_box(float4 b0, float2 b1, V3 o, 
 // against its pair's entry; the results meet per pixel as (ordered t, index) keys (atomicMin =
 // the reference's accept rule).  Pair word: pixel | entry << 6 | cull-sure << 12.
 // Returns the number of pairs, or 0xffffffff when they do not fit (nothing written).
+template <int CAP = 64>
 __device__ __forceinline__ unsigned build_pairs(const Cand& cand, int lane, unsigned short* __restrict__ pairs, unsigned cap) {
-    const unsigned pc = (unsigned)(__builtin_popcount(cand.lo) + __builtin_popcount(cand.hi));
+    const unsigned pc = (unsigned)(__builtin_popcount(cand.lo) + (CAP > 32 ? __builtin_popcount(cand.hi) : 0));
     unsigned incl = pc;
 #pragma unroll
     for (int ofs = 1; ofs < 64; ofs <<= 1) {
@@ -1442,7 +1477,7 @@ __device__ __forceinline__ unsigned build_pairs(const Cand& cand, int lane, unsi
     if (total > cap) return 0xffffffffu;
     unsigned at = incl - pc;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < (CAP > 32 ? 2 : 1); ++half) {
         unsigned m = half ? cand.hi : cand.lo;
         const unsigned sm = half ? cand.sure_hi : cand.sure_lo;
         while (m != 0u) {
@@ -1458,8 +1493,8 @@ __device__ __forceinline__ unsigned build_pairs(const Cand& cand, int lane, unsi
 }
 
 // One sample: all pairs against the rays ray_of(pixel); minima into keys[pixel].  All 64 lanes active.
-template <class RayOf>
-__device__ __forceinline__ void trace_pairs(StageArea& area, const int* ent, const unsigned short* __restrict__ pairs,
+template <class Area, class RayOf>
+__device__ __forceinline__ void trace_pairs(Area& area, const int* ent, const unsigned short* __restrict__ pairs,
                                             unsigned n_pairs, int lane, RayOf ray_of, unsigned long long* keys) {
     for (unsigned base = 0; base < n_pairs; base += 64u) {
         const unsigned j = base + (unsigned)lane;
@@ -1501,7 +1536,11 @@ __device__ __forceinline__ void trace_pairs(StageArea& area, const int* ent, con
 // than 32 survivors (or without a list) and wave-samples off the hot direction chain take the
 // tree itself (bvh_trace).  Heavy tiles keep the 8-wave scheme: the master wave publishes c3, merges the slices' keys and
 // checks the winner's chain.
-template <bool VREC, int OCC, int WAVES, bool BVH = false, bool MAT = false>
+// FULL: the launch policy of a full frame as compile-time constants — light tiles dealt in groups of four, no row slabs except
+// four for the list world's heaviest class — instead of the decode of split_packed that small launches (one rank's strips),
+// test hooks and the tuning build need (round 3 decoded it in every launch: +2 % on the bench frame's shading kernel, same-box
+// A/B in profiles/r4/ab_r2_vs_head.txt).
+template <bool VREC, int OCC, int WAVES, bool BVH = false, bool MAT = false, bool FULL = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
 shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
@@ -1518,9 +1557,15 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     __shared__ unsigned long long best_key[64];   // per pixel: min over the waves of (ordered t, index)
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
-    __shared__ StageArea lrec[VREC ? WAVES : 1];       // this wave's staged list entries: forms, then exact records (4 KB per wave)
-    __shared__ float lqw[VREC ? WAVES : 1][64];        // slack + radius of the fifth form of the staged entries
-    __shared__ int lent[VREC ? WAVES : 1][64];         // pool words of the staged entries
+    // kStage: list entries one wavefront stages (forms, then exact records).  The BVH mode stages 32: with its slots and leaf
+    // boxes next to them a 64-entry area made the block 76 KB = two blocks per CU = 4 wavefronts per SIMD; at 32 the block is
+    // below 53 KB and three fit.  (Light tiles never hold more than 32 entries; a heavy tile's slice beyond its staged part
+    // takes the keyed scalar walk.)
+    constexpr int kStage = BVH ? 32 : 64;
+    using Area = typename std::conditional<BVH, StageArea32, StageArea>::type;
+    __shared__ Area lrec[VREC ? WAVES : 1];                // this wave's staged list entries: forms, then exact records (4 KB per wave; BVH: 2 KB)
+    __shared__ float lqw[VREC ? WAVES : 1][kStage];        // slack + radius of the fifth form of the staged entries
+    __shared__ int lent[VREC ? WAVES : 1][kStage];         // pool words of the staged entries
     // balanced candidate walk of light tiles (8-wave blocks only: the LDS of 16-wave blocks is spoken for)
     constexpr int kPairCap = (VREC && WAVES <= 8) ? 512 : 1;
     __shared__ unsigned short lpairs[(VREC && WAVES <= 8) ? WAVES : 1][kPairCap];   // (pixel | entry << 6 | cull-sure << 12)
@@ -1528,13 +1573,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     __shared__ __attribute__((aligned(16))) int lpath[BVH ? WAVES : 1][32];        // BVH mode: node indices of the tile's reference path
     // BVH mode, staged tiles: per list entry its slot, (leaf depth | first level to test << 8 | 1 << 16 when more than
     // kChainBatch levels remain), and the node indices of those levels — the chain test then needs ONE round of loads
-    __shared__ int lslot[BVH ? WAVES : 1][BVH ? 64 : 1];
-    __shared__ int linfo[BVH ? WAVES : 1][BVH ? 64 : 1];
-    __shared__ __attribute__((aligned(16))) int lnodes[BVH ? WAVES : 1][BVH ? 64 : 1][kChainBatch];
+    __shared__ int lslot[BVH ? WAVES : 1][BVH ? kStage : 1];
+    __shared__ int linfo[BVH ? WAVES : 1][BVH ? kStage : 1];
+    __shared__ __attribute__((aligned(16))) int lnodes[BVH ? WAVES : 1][BVH ? kStage : 1][kChainBatch];
     // ... and the box of its LEAF (min.xyz, max.x | max.yz): a ray whose hit point lies strictly inside it passes every box of the chain
     // (hit_inside_leaf_box), so the common sample needs no node loads at all
-    __shared__ float4 lbox0[BVH ? WAVES : 1][BVH ? 64 : 1];
-    __shared__ float2 lbox1[BVH ? WAVES : 1][BVH ? 64 : 1];
+    __shared__ float4 lbox0[BVH ? WAVES : 1][BVH ? kStage : 1];
+    __shared__ float2 lbox1[BVH ? WAVES : 1][BVH ? kStage : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1552,9 +1597,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     // is 64 x (time of one sample); the (pixel, entry) pairs of one sample split evenly over the slabs, and the blocks
     // that take the slabs run side by side — the longest chain of a launch gets shorter by the split factor, down to
     // the master wave's own per-sample work.
+    auto split_of = [&](int c) -> unsigned {   // log2 of the row slabs a heavy tile of class c is dealt out as
+        if (FULL) return (!BVH && c == 0) ? 2u : 0u;
+        return (split_packed >> (3 * c)) & 7u;
+    };
     unsigned total_heavy = 0;
 #pragma unroll
-    for (int c = 0; c < kHeavyClasses; ++c) total_heavy += w.counters[kCtrQueueLen + c] << ((split_packed >> (3 * c)) & 7u);
+    for (int c = 0; c < kHeavyClasses; ++c) total_heavy += w.counters[kCtrQueueLen + c] << split_of(c);
 #ifndef CRT_PRIO
 #define CRT_PRIO 1
 #endif
@@ -1574,11 +1623,11 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             int c = 0;
             unsigned idx = item;
             for (; c < kHeavyClasses - 1; ++c) {
-                const unsigned len = w.counters[kCtrQueueLen + c] << ((split_packed >> (3 * c)) & 7u);
+                const unsigned len = w.counters[kCtrQueueLen + c] << split_of(c);
                 if (idx < len) break;
                 idx -= len;
             }
-            const unsigned sl = (split_packed >> (3 * c)) & 7u;
+            const unsigned sl = split_of(c);
             const int sub = (int)(idx & ((1u << sl) - 1u));
             const int tile_id = (int)w.queue[(size_t)c * w.tiles_total + (idx >> sl)];
             const uint2 desc = w.tile_desc[tile_id];
@@ -1591,10 +1640,11 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const uint32_t* __restrict__ lst = w.pool + desc.x;
             if (timeline) tl_heavy = ((unsigned long long)(unsigned)n_src << 24) | (unsigned)tile_id;
             // The master wave (wave 0) has no slice — it runs the rejection draws of the hit branch on a copy of the streams while
-            // the other WAVES - 1 waves trace (render_pixel<.., SPEC>) — unless (BVH world) seven slices would not fit four staging
-            // chunks of 64 each: the 1 800-2 000-entry pole tiles of C5 then take eight slices, the master tracing one itself
-            // (seven would send them to the tree walk: 10 -> 47 ms, measured in round 2).
-            const int slice_waves = (BVH && n_src > (WAVES - 1) * 256) ? WAVES : WAVES - 1;
+            // the other WAVES - 1 waves trace (render_pixel<.., SPEC>) — unless (BVH world) seven slices would not fit the staging
+            // areas (7 x 32 entries): then eight slices, the master tracing one itself.  An unstaged winner costs the master three
+            // dependent global loads per sample (slot, path, nodes): the two 247-entry pole tiles of the C3 frame took 440 or 860 us
+            // with seven slices of 36, depending on where the binning's atomics had left the winners in the list.
+            const int slice_waves = (BVH && n_src > (WAVES - 1) * (BVH ? 32 : 64)) ? WAVES : WAVES - 1;
             const int swave = (slice_waves == WAVES) ? wave : wave - 1;
             const int per = (n_src + slice_waves - 1) / slice_waves;
             const int k0 = (swave < 0) ? 0 : min(n_src, swave * per), k1 = (swave < 0) ? 0 : min(n_src, k0 + per);
@@ -1616,42 +1666,19 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             // Master/worker: wave 0 owns the pixels' RNG streams, generates the 64 rays of each
             // sample and shades; the other waves only trace.  Two barriers per sample:
             // B1 "rays are in LDS", B2 "partial minima are in LDS".
-            // this wave's slice: the first 64 entries are staged in LDS like a light tile's list
-            // BVH mode: a slice of up to 64 entries is staged once like below; up to 256 entries pass through the staging
-            // area in chunks of 64 per sample (candidate masks kept per chunk); tiles without a list or with longer slices
-            // walk the tree, wave 0 alone.  (The unstaged walks of the list world order ties by index, not by the tree's rule.)
-            // (from the LONGEST slice, `per`: the mode must be the same for every wave of the block — the waves of a tree tile
-            // skip the per-sample barriers the others wait at; a wave with a shorter slice just stages fewer entries)
-            const int s_chunks = (BVH && !walk_all) ? (min(per, n_src) + 63) / 64 : 1;
-            // (the candidate masks and entries of the up to four chunks are what this kernel spills: without the chunked mode it has
-            // 116 B of scratch per lane instead of 332 — and the same C3 frame time, 1.18 ms, while C5's pole tiles would walk the
-            // tree: 95 ms.  Measured, kept.)
-            const bool tree_tile = BVH && (walk_all || s_chunks > 4 || !VREC);
-            const bool multi = BVH && !tree_tile && s_chunks > 1;
-            const int n_lds = (VREC && !walk_all && !multi && !tree_tile) ? min(64, cnt_w) : 0;
+            // this wave's slice: its first kStage entries are staged in LDS like a light tile's list (per-pixel candidate masks,
+            // balanced pair walk); the rest of a longer slice is walked with scalar-operand records — in the BVH mode in the
+            // tree's tie order (walk_list_strided_keyed; rounds 2-3 passed up to four chunks of 64 through the staging area per
+            // sample instead, whose candidate masks were 24 VGPRs live across the sample loop: most of that kernel's scratch).
+            // Tiles without a list walk the tree, wave 0 alone.
+            const bool tree_tile = BVH && (walk_all || !VREC);
+            const int n_lds = (VREC && !walk_all && !tree_tile) ? min(kStage, cnt_w) : 0;
             int slice_mine = 0;
             Cand cand = {0u, 0u, 0u, 0u};
             if (n_lds > 0) {   // per-pixel candidates among the staged entries of this wave's slice
                 slice_mine = (lane < n_lds) ? (int)lst[swave + lane * slice_waves] : 0;
-                stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
-                                 global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
-            }
-            Cand cc[4];
-            int e_c[4], q_c[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { cc[c] = Cand{0u, 0u, 0u, 0u}; e_c[c] = 0; q_c[c] = 0; }
-            if (multi) {
-                const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ly);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (c < s_chunks) {
-                        const int n = min(64, cnt_w - 64 * c);
-                        e_c[c] = (lane < n) ? (int)lst[swave + (64 * c + lane) * slice_waves] : 0;
-                        stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, e_c[c], n, lane, x, gy, cc[c]);
-                        if (!lane_valid) cc[c].lo = cc[c].hi = 0u;
-                        q_c[c] = (lane < n) ? (int)(((unsigned)e_c[c] & kCullSureBit) | (unsigned)(0x7fffffff - bvh.partner[e_c[c] & 0x7fffffff])) : 0;
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                stage_candidates<kStage>(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
+                                         global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
             }
             // BVH mode: the levels of the tree proven hit for every ray of the tile along its first entry's path (every wave
             // works it out for itself, into its own lpath), and for a staged slice — like a light tile's list — per entry:
@@ -1667,7 +1694,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, tly0));
                 first_level_h = __builtin_amdgcn_readfirstlane(
                     tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[wave], lane));
-                if (!multi && n_lds > 0) {
+                if (n_lds > 0) {
                     if (lane < n_lds) {
                         const int slot = slice_mine & 0x7fffffff;
                         // key: (tie order, 22 bits: smaller wins = later leaf, first in its leaf) | wave | position (host: at most 2^22 triangles)
@@ -1705,32 +1732,18 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             unsigned slice_pairs = 0xffffffffu;   // balanced walk of the staged part of the slice (rays and keys are in LDS anyway)
             if (VREC && WAVES <= 8 && n_lds > 0 && dbg_pairs != 0) {
                 if (!lane_valid) cand.lo = cand.hi = 0u;
-                slice_pairs = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
+                slice_pairs = build_pairs<kStage>(cand, lane, lpairs[wave], (unsigned)kPairCap);
             }
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
-              if (multi) {   // BVH mode, long slice: every chunk's exact records pass through the staging area again
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) {
-                      if (c >= s_chunks) continue;
-                      __builtin_amdgcn_wave_barrier();
-                      if (lane < min(64, cnt_w - 64 * c)) {
-                          const float4* r = reinterpret_cast<const float4*>(rec + (size_t)(e_c[c] & 0x7fffffff) * kRecFloats);
-                          lrec[wave][0][lane] = r[0]; lrec[wave][1][lane] = r[1]; lrec[wave][2][lane] = r[2]; lrec[wave][3][lane] = r[3];
-                          lent[wave][lane] = q_c[c];
-                      }
-                      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                      __builtin_amdgcn_wave_barrier();
-                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                      trace_candidates(lrec[wave], lent[wave], cc[c], d2, closest, hit_idx);
-                  }
-                  return;
-              }
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (slice_pairs != 0xffffffffu)
                     trace_pairs(lrec[wave], lent[wave], lpairs[wave], slice_pairs, lane,
                                 [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key);
-                else if (n_lds > 0) trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
-                if (interleaved) walk_list_strided<true>(rec, lst, swave, slice_waves, n_lds, cnt_w, lane, d2, closest, hit_idx);
+                else if (n_lds > 0) trace_candidates<kStage>(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
+                if (BVH) {   // (a tree tile never comes here) the unstaged rest of the slice, keys in the tree's order, tagged: position bit 5
+                    if (interleaved) walk_list_strided_keyed<true>(rec, lst, bvh.partner, ((unsigned)wave << 6) | 32u, swave, slice_waves, n_lds,
+                                                                   cnt_w, lane, d2, closest, hit_idx);
+                } else if (interleaved) walk_list_strided<true>(rec, lst, swave, slice_waves, n_lds, cnt_w, lane, d2, closest, hit_idx);
                 else walk<true>(rec, k0, k1, [](int k) { return k; }, d2, closest, hit_idx);   // no list: a range of all triangles
               }
             };
@@ -1759,13 +1772,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 int tl_sample_bvh = 0;   // timeline mode: (slices done, chains checked) per sample of the first blocks' first tile
                 render_pixel<true, false, false, !MAT, MAT>(p, x, ly, shade_n, state, rgb, lane_valid,
                              [&](V3 d1, V3, float& closest, int& hit_idx, auto&&... hit_branch_draws) {
-                    const V3 c1 = rot0_exact(bt.rot, d1);
-                    const V3 c2 = chain_next<true>(bt.rot, c1);
-                    const V3 c3 = chain_next<true>(bt.rot, c2);
-                    const V3 c4 = chain_next<true>(bt.rot, c3);
-                    const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
-                                           fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
-                    const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f && dbg_repeat_in != -77;
+                    V3 c3;   // (hot_chain: the chain's other elements are recomputed in the rare branches that need them)
+                    const bool hot = hot_chain(d1, c3) && dbg_repeat_in != -77;
                     ray_d[0][lane] = c3.x;
                     ray_d[1][lane] = c3.y;
                     ray_d[2][lane] = c3.z;
@@ -1787,7 +1795,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 #ifdef CRT_DBG_NOCHAIN_HEAVY   // timing experiment only (wrong pixels where a chain fails)
                     if (hot && kbest != ~0ull) {
                         const int qk0 = (int)(unsigned)(kbest & 0xffffffffull);
-                        slot = multi ? bt.partner[0x7fffffff - qk0] : lslot[(qk0 >> 6) & 7][qk0 & 63];
+                        slot = (qk0 & 32) ? bt.partner[0x3fffff - ((qk0 >> 9) & 0x3fffff)] : lslot[(qk0 >> 6) & 7][qk0 & 31];
                         alone = false;
                     }
                     if (false) {
@@ -1795,11 +1803,11 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     if (hot && kbest != ~0ull) {
 #endif
                         const int qk = (int)(unsigned)(kbest & 0xffffffffull);
-                        if (multi) {   // chunked slices: the key is the tie order alone
-                            slot = bt.partner[0x7fffffff - qk];
-                            alone = !chain_ok(bt, slot, first_level, lpath[0], o, c1, c2, c3);
-                        } else {       // staged slices: the winner's wave and position are in the key
-                            const int sw = (qk >> 6) & 7, kw = qk & 63;
+                        if (qk & 32) {   // an unstaged entry of a long slice: the slot through the tie order, the chain through the tables
+                            slot = bt.partner[0x3fffff - ((qk >> 9) & 0x3fffff)];
+                            alone = !chain_ok(bt, slot, first_level, lpath[0], o, d1, unit_vector_fast_ng(d1), c3);   // hot lane: c1 = d1, c2 = F(d1)
+                        } else {         // staged: the winner's wave and position are in the key
+                            const int sw = (qk >> 6) & 7, kw = qk & 31;
                             slot = lslot[sw][kw];
                             const int info = linfo[sw][kw];
                             const bool inside = hit_inside_leaf_box(lbox0[sw][kw], lbox1[sw][kw], o, c3, key_t(kbest));
@@ -1808,8 +1816,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                             } else if (inside) {
                                 alone = false;
                             } else if (info >> 16) {   // more levels than one batch: the general routine (global loads)
-                                alone = !chain_ok(bt, slot, first_level, lpath[0], o, c1, c2, c3);
+                                alone = !chain_ok(bt, slot, first_level, lpath[0], o, d1, unit_vector_fast_ng(d1), c3);
                             } else {
+                                const V3 c1 = d1, c2 = unit_vector_fast_ng(d1);   // hot lane: rotate(., 0) is the identity on its directions
                                 const int depth = info & 31, first_k = (info >> 8) & 31;
                                 int node[kChainBatch];
                                 float4 na[kChainBatch], nb[kChainBatch];
@@ -1836,14 +1845,18 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                             }
                         }
                     }
-                    if (alone) {   // per lane, over the tile's whole list
+                    if (alone) {   // per lane, over the tile's whole list, with the literal chain
+                        const V3 c1 = rot0_exact(bt.rot, d1);
+                        const V3 c2 = chain_next<true>(bt.rot, c1);
+                        const V3 c3l = chain_next<true>(bt.rot, c2);
+                        const V3 c4 = chain_next<true>(bt.rot, c3l);
                         const V3 c5 = rot0(bt.rot, unit_vector(c4));
-                        const int mode = hot ? 0 : (same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2));
+                        const int mode = same_bits(c4, c3l) ? 0 : (same_bits(c5, c4) ? 0 : (same_bits(c5, c3l) ? 1 : 2));
                         int gex[8];
                         int n_ex = 0;
                         for (;;) {
-                            const int qg = general_winner_all(bt, rec, lst, n_src, gex, n_ex, o, c1, c2, c3, c4, mode, slot);
-                            if (qg < 0 || chain_ok_general(bt, slot, o, c1, c2, c3, c4, mode)) break;
+                            const int qg = general_winner_all(bt, rec, lst, n_src, gex, n_ex, o, c1, c2, c3l, c4, mode, slot);
+                            if (qg < 0 || chain_ok_general(bt, slot, o, c1, c2, c3l, c4, mode)) break;
                             if (n_ex == 8) {   // more unreachable winners than this lane keeps track of: the tree itself decides
                                 BvhView view;
                                 view.nodes = bt.nodes;
@@ -1868,7 +1881,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         ++tl_sample_bvh;
                     }
                 }, mv);
-            } else if (wave == 0) {
+            } else if (!BVH && wave == 0) {
                 long long tc_prev = stats ? (long long)clock64() : 0, tc_setup = 0, tc_trace = 0, tc_wait = 0;
                 int tl_sample = 0;   // timeline mode: the first blocks log two time stamps per sample of their first shared tile
                 render_pixel<true, false, true, !MAT, MAT>(p, x, ly, shade_n, state, rgb, lane_valid,
@@ -1933,7 +1946,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     // through "its" chunk and then helps with whatever chunk still has tiles.
     // (bits 30..31 of split_packed: light tiles WITH geometry are dealt out as 1 << lsl row slabs too — for launches with far
     // more waves than such tiles, where one wave's 64-sample chain over a whole tile is the longest thing left; list world)
-    const unsigned lsl = BVH ? 0u : (split_packed >> 30) & 3u;
+    const unsigned lsl = (BVH || FULL) ? 0u : (split_packed >> 30) & 3u;
     unsigned light_len[kLightClasses], n_light = 0;
 #pragma unroll
     for (int c = 0; c < kLightClasses; ++c) {
@@ -1947,7 +1960,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     // (a launch with few tiles per CU — one rank's strips of a multi-GPU split — deals them ONE at a time, bits 27..29 of
     // split_packed: its waves far outnumber its tiles with geometry, and a wave that takes four neighbours with geometry
     // one after the other was the last to end, 250 us after waves that found only sky had gone: profiles/r3_tiled)
-    const unsigned kLightGroup = max(1u, (split_packed >> 27) & 7u);
+    const unsigned kLightGroup = FULL ? 4u : max(1u, (split_packed >> 27) & 7u);
     const unsigned n_groups = (n_light + kLightGroup - 1) / kLightGroup;
     int chunk = (int)((blockIdx.x * WAVES + wave) % kLightChunks);
     while (true) {
@@ -2008,15 +2021,15 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             // (a light tile never holds more than the heavy threshold, at most 64 entries — bin_alloc_kernel queues anything longer
             // as a shared tile — so one staging chunk serves it; rounds 1-2 carried two more paths here, for 65..256 and longer
             // lists, that no launch could reach and that cost the kernel registers)
-            if (!VREC || desc.y == kNoList) {   // no list (pool overflow): every sample walks the tree
+            if (!VREC || desc.y == kNoList || cnt > kStage) {   // no list (pool overflow; or, never in a shipped launch, a light tile longer than the staging area): every sample walks the tree
                 render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
                     V3 used;
                     bvh_trace<true>(view, rec, o, d1, 0, closest, hit_idx, used);
                 }, mv);
                 continue;
             }
-            stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, cnt, lane, px,
-                             global_row(p.row_begin, p.strip_rows, p.strip_step, ply), cand);
+            stage_candidates<kStage>(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, cnt, lane, px,
+                                     global_row(p.row_begin, p.strip_rows, p.strip_step, ply), cand);
             // levels of the tree proven hit for every ray of this tile (along the first entry's path)
             const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
             const int first_level = __builtin_amdgcn_readfirstlane(
@@ -2056,32 +2069,35 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (!store) cand.lo = cand.hi = 0u;
             unsigned bp = 0xffffffffu;
-            if (WAVES <= 8) bp = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
+            if (WAVES <= 8) bp = build_pairs<kStage>(cand, lane, lpairs[wave], (unsigned)kPairCap);
             render_pixel<true, false, false, false, MAT>(p, px, ply, shade_n, state, rgb, store, [&](V3 d1, V3, float& closest, int& hit_idx) {
-                const V3 c1 = rot0_exact(view.rot, d1);
-                const V3 c2 = chain_next<true>(view.rot, c1);
-                const V3 c3 = chain_next<true>(view.rot, c2);
-                const V3 c4 = chain_next<true>(view.rot, c3);
-                const float lo = fminf(fminf(fminf(fabsf(c1.x), fabsf(c1.y)), fminf(fabsf(c1.z), fabsf(c2.x))),
-                                       fminf(fminf(fabsf(c2.y), fabsf(c2.z)), fminf(fminf(fabsf(c3.x), fabsf(c3.y)), fabsf(c3.z))));
-                const bool hot = same_bits(c4, c3) && lo >= 9.094947017729282e-13f && dbg_repeat_in != -77;   // -77: test hook, every lane takes the general path
-                if (!hot) {   // off the hot chain (0.01 % of rays): this lane alone, with the chain element of every depth
-                    const V3 c5 = rot0(view.rot, unit_vector(c4));
-                    const int mode = same_bits(c5, c4) ? 0 : (same_bits(c5, c3) ? 1 : 2);
-                    const unsigned masks[2] = {cand.lo, cand.hi};
-                    unsigned gex[2] = {0u, 0u};
-                    for (;;) {
-                        int slot = -1;
-                        const int q = general_winner(bt, rec, lst, cnt, masks, gex, 2, o, c1, c2, c3, c4, mode, slot);
-                        if (q < 0 || chain_ok_general(bt, slot, o, c1, c2, c3, c4, mode)) { hit_idx = slot; break; }
-                        for (int k = 0; k < cnt; ++k)
-                            if ((int)(lst[k] & 0x7fffffffu) == slot) {
-                                if (k < 32) gex[0] |= 1u << k;
-                                else gex[1] |= 1u << (k - 32);
-                            }
+                // Only c3 (and d1) stay live across the walk: the chain's other elements are recomputed inside the rare branches
+                // that need them (a lane off the hot chain; a winner whose chain of boxes needs node loads).
+                V3 c3;
+                const bool hot = hot_chain(d1, c3) && dbg_repeat_in != -77;   // -77: test hook, every lane takes the general path
+                if (__builtin_amdgcn_ballot_w64(!hot) != 0ull) {
+                    if (!hot) {   // off the hot chain (0.01 % of rays): this lane alone, with the literal chain element of every depth
+                        const V3 c1 = rot0_exact(view.rot, d1);
+                        const V3 c2 = chain_next<true>(view.rot, c1);
+                        const V3 c3l = chain_next<true>(view.rot, c2);
+                        const V3 c4 = chain_next<true>(view.rot, c3l);
+                        const V3 c5 = rot0(view.rot, unit_vector(c4));
+                        const int mode = same_bits(c4, c3l) ? 0 : (same_bits(c5, c4) ? 0 : (same_bits(c5, c3l) ? 1 : 2));
+                        const unsigned masks[2] = {cand.lo, cand.hi};
+                        unsigned gex[2] = {0u, 0u};
+                        for (;;) {
+                            int slot = -1;
+                            const int q = general_winner(bt, rec, lst, cnt, masks, gex, 2, o, c1, c2, c3l, c4, mode, slot);
+                            if (q < 0 || chain_ok_general(bt, slot, o, c1, c2, c3l, c4, mode)) { hit_idx = slot; break; }
+                            for (int k = 0; k < cnt; ++k)
+                                if ((int)(lst[k] & 0x7fffffffu) == slot) {
+                                    if (k < 32) gex[0] |= 1u << k;
+                                    else gex[1] |= 1u << (k - 32);
+                                }
+                        }
                     }
                 }
-                unsigned excl = 0u, excl_hi = 0u;
+                unsigned excl = 0u;
                 for (bool first = true;; first = false) {
                     int q = -1;
                     float t_win = 0.0f;   // the winner's t (the reference's rec.t): the hit point o + t * c3 decides whether the chain needs loads
@@ -2103,14 +2119,13 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     } else {
                         Cand rest = cand;
                         rest.lo &= ~excl;
-                        rest.hi &= ~excl_hi;
                         float tb = FLT_MAX;
-                        trace_candidates(lrec[wave], lent[wave], rest, c3, tb, q);
+                        trace_candidates<kStage>(lrec[wave], lent[wave], rest, c3, tb, q);
                         t_win = tb;
                     }
                     int slot = -1;
                     bool bad = false;
-                    const int kw = q & 63;   // the winner's position in the staged list
+                    const int kw = q & 31;   // the winner's position in the staged list (kStage = 32)
                     // the winner's hit point strictly inside its leaf's box: every box of its chain is passed, no loads
                     const bool chain_sure = q >= 0 && hot && hit_inside_leaf_box(lbox0[wave][kw], lbox1[wave][kw], o, c3, t_win);
                     const bool need_chain = q >= 0 && hot && !chain_sure;
@@ -2120,6 +2135,8 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 #else
                     if (__builtin_amdgcn_ballot_w64(need_chain) != 0ull && need_chain) {
 #endif
+                        // (hot lane: rotate(., 0) is the identity on its directions, so c1 = d1 and c2 = one normalisation on)
+                        const V3 c1 = d1, c2 = unit_vector_fast_ng(d1);
                         const int info = linfo[wave][kw];
                         if (info >> 16) {   // more levels than one batch: the general routine (global loads)
                             bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
@@ -2154,17 +2171,15 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         closest = 0.0f;   // not used after the traversal
                         break;
                     }
-                    if (bad) {   // this pixel's winner is not reachable through the tree: exclude it and look again
-                        if (kw < 32) excl |= 1u << kw;
-                        else excl_hi |= 1u << (kw - 32);
-                    }
+                    if (bad) excl |= 1u << kw;   // this pixel's winner is not reachable through the tree: exclude it and look again
                 }
             }, mv);
             continue;
         }
-        if (VREC && cnt > 0)   // all 64 lanes, before any lane leaves: lanes off the image classify a valid pixel
-            stage_candidates(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, n0, lane, min(x, p.nx - 1),
-                             global_row(p.row_begin, p.strip_rows, p.strip_step, min(ly, p.row_count - 1)), cand);
+        // (from here on: the list world; a BVH-world tile that comes this far has no survivors — sky)
+        if (!BVH && VREC && cnt > 0)   // all 64 lanes, before any lane leaves: lanes off the image classify a valid pixel
+            stage_candidates<kStage>(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, n0, lane, min(x, p.nx - 1),
+                                     global_row(p.row_begin, p.strip_rows, p.strip_step, min(ly, p.row_count - 1)), cand);
         if (stats && VREC && cnt > 0) {   // diagnostics: per-pixel candidates vs the tile's list
             const unsigned pc = (unsigned)(__builtin_popcount(cand.lo) + __builtin_popcount(cand.hi));
             unsigned mx = pc, sm = pc;
@@ -2186,9 +2201,9 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         // fetches the ray of its pair's pixel with ds_bpermute and the results meet per pixel in LDS
         // as (ordered t, index) keys (atomicMin = the reference's accept rule).
         unsigned n_pairs = 0xffffffffu;
-        if (VREC && WAVES <= 8 && cnt > 0 && dbg_pairs != 0) {
+        if (!BVH && VREC && WAVES <= 8 && cnt > 0 && dbg_pairs != 0) {
             if (!lane_ok) cand.lo = cand.hi = 0u;   // lanes off the image replay a pixel: no pairs of their own
-            n_pairs = build_pairs(cand, lane, lpairs[wave], (unsigned)kPairCap);
+            n_pairs = build_pairs<kStage>(cand, lane, lpairs[wave], (unsigned)kPairCap);
         }
         const bool pair_mode = n_pairs != 0xffffffffu;
         if (stats && VREC && cnt > 0 && lane == 0) {   // diagnostics: did the pairs fit, how many
@@ -2197,7 +2212,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         }
         if (cnt == 0) {   // background only (most tiles of a typical frame)
             if (lane_ok) render_sky_pixel(p, x, ly, state, rgb);
-        } else if (pair_mode) {   // all 64 lanes stay active (ds_bpermute reads lanes); off-image lanes replay a valid pixel, unstored
+        } else if (!BVH && pair_mode) {   // all 64 lanes stay active (ds_bpermute reads lanes); off-image lanes replay a valid pixel, unstored
             render_pixel<true, false, true, false, MAT>(p, min(x, p.nx - 1), min(ly, p.row_count - 1), shade_n, state, rgb, lane_ok,
                          [&](V3, V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
@@ -2217,12 +2232,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 closest = 0.0f;   // not used after the traversal
               }
             }, mv);
-        } else if (lane_ok) {
+        } else if (!BVH && lane_ok) {
             render_pixel<true, false, true, false, MAT>(p, x, ly, shade_n, state, rgb, true,
                          [&](V3, V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
                 if (VREC) {
-                    trace_candidates(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
+                    trace_candidates<kStage>(lrec[wave], lent[wave], cand, d2, closest, hit_idx);
                     walk<true>(rec, 64, cnt, [&](int k) { return __builtin_amdgcn_readlane(mine1, k - 64); }, d2, closest, hit_idx);
                 } else {
                     walk<true>(rec, 0, min(cnt, 64), [&](int k) { return __builtin_amdgcn_readlane(mine0, k); }, d2, closest, hit_idx);
@@ -2495,6 +2510,8 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     if (d_bvh_tiles != nullptr) light_split = 0u;
     split_packed |= light_split << 30;
     ShadeFn fn;
+#ifdef CRT_TUNING   // block sizes and occupancies no shipped launch selects exist in tuning builds only (they were 7 of the 12
+                    // instantiations of the library's largest kernel)
     if (group == 4) {   // experiment (CRT_SHADE_GROUP=4): half as many waves parked per shared tile, more blocks free for light tiles at once
         occ = 6;
         fn = shade_tiles_kernel<true, 6, 4>;
@@ -2508,13 +2525,25 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
         fn = vrec ? (occ == 4 ? shade_tiles_kernel<true, 4, 16> : shade_tiles_kernel<true, 8, 16>)
                   : (occ == 4 ? shade_tiles_kernel<false, 4, 16> : shade_tiles_kernel<false, 8, 16>);
     }
+#else
+    fn = vrec ? shade_tiles_kernel<true, 6, 8> : shade_tiles_kernel<false, 6, 8>;
+    (void)occ;
+#endif
+    // the full-frame policy as compile-time constants (shade_tiles_kernel<.., FULL>) when this launch's policy is exactly that
+    unsigned full_packed = (4u << 27) | (d_bvh_tiles == nullptr ? 2u : 0u);
+    const bool full = split_packed == full_packed && group == 8;
+    if (full && d_bvh_tiles == nullptr && materials == nullptr && vrec) fn = shade_tiles_kernel<true, 6, 8, false, false, true>;
     if (d_bvh_tiles) {   // the tree as the world (shade_tiles_kernel<.., BVH = true>)
         group = 8;
+        heavy = std::min(heavy, 32);   // its staging area holds 32 entries: a light tile must fit
 #ifndef CRT_BVH_OCC
-#define CRT_BVH_OCC 4   // the block's 62 KB of LDS allow two blocks per CU = 4 waves/SIMD; asked for 6, the compiler gives up on the
-                        // target and takes 220 VGPRs = 2 waves/SIMD (C3 2.46 ms, C5 17.0); held to 128 VGPRs: 1.70 / 10.5 ms (sweep_bvh.txt)
+#define CRT_BVH_OCC 4   // round 4: the BVH mode stages 32 entries per wavefront (block 45 KB of LDS: three blocks per CU would fit) but at the 80 VGPRs of
+                        // six waves per SIMD it spills into its sample loops: 128 VGPRs = two blocks per CU is 6 % faster on C3, equal on C5 (profiles/r4/bvh_occ_ab2.txt).
+                        // (Rounds 2-3: 76 KB = two blocks = 4 waves/SIMD at 128 VGPRs; asked for 6 with that LDS the compiler gave up on
+                        // the target and took 220 VGPRs = 2 waves/SIMD: sweep_bvh.txt)
 #endif
-        fn = materials ? shade_tiles_kernel<true, CRT_BVH_OCC, 8, true, true> : shade_tiles_kernel<true, CRT_BVH_OCC, 8, true>;
+        fn = materials ? shade_tiles_kernel<true, CRT_BVH_OCC, 8, true, true>
+                       : (full ? shade_tiles_kernel<true, CRT_BVH_OCC, 8, true, false, true> : shade_tiles_kernel<true, CRT_BVH_OCC, 8, true>);
         if (bvh_force_general) dbg_repeat = -77;
     } else if (materials) {   // LambertShade with a material per triangle: the staged 8-wave kernel
         group = 8;
