@@ -155,6 +155,22 @@ def hip_crop(scene, camera, win, spp):
     return d.cpu().numpy().reshape(r1 - r0, NX, 3)[:, c0:c1]
 
 
+def timed_frames(frame, n, warm_s=0.2):
+    """ms per call of `frame` (which only enqueues): untimed calls for >= warm_s first — building a scene on the host in between
+    lets the shader clock drop, and ten frames are over before it is back — then n calls between two synchronisations."""
+    import torch
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        for _ in range(5):
+            frame()
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n):
+        frame()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t1) / n * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,14 +300,7 @@ def main():
         api.render_rows(scene, cam_near, st_near, NX, NY, args.spp, 0, NY, buf, stream=stream)
         torch.cuda.synchronize()
         st_n = api.tiled_stats(False)
-        for _ in range(3):
-            api.render_rows(scene, cam_near, st_near, NX, NY, args.spp, 0, NY, buf, stream=stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            api.render_rows(scene, cam_near, st_near, NX, NY, args.spp, 0, NY, buf, stream=stream)
-        torch.cuda.synchronize()
-        ms_near = (time.perf_counter() - t1) / 10 * 1e3
+        ms_near = timed_frames(lambda: api.render_rows(scene, cam_near, st_near, NX, NY, args.spp, 0, NY, buf, stream=stream), 10)
         filling = {"camera": "lookfrom (0,0,300) lookat (0,0,0): the mesh covers every pixel",
                    "ms_per_frame": ms_near, "Mrays/s": NX * NY * args.spp / ms_near / 1e3,
                    "tiles_with_geometry_frac": 1.0 - st_n[8] / max(st_n[4], 1),
@@ -311,14 +320,7 @@ def main():
         api.render_rows(scene_b, camera, st_bb, nxb, nyb, args.spp, 0, nyb, buf, stream=stream)
         torch.cuda.synchronize()
         st_s = api.tiled_stats(False)
-        for _ in range(5):
-            api.render_rows(scene_b, camera, st_bb, nxb, nyb, args.spp, 0, nyb, buf, stream=stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            api.render_rows(scene_b, camera, st_bb, nxb, nyb, args.spp, 0, nyb, buf, stream=stream)
-        torch.cuda.synchronize()
-        ms_2 = (time.perf_counter() - t1) / 20 * 1e3
+        ms_2 = timed_frames(lambda: api.render_rows(scene_b, camera, st_bb, nxb, nyb, args.spp, 0, nyb, buf, stream=stream), 20)
         second = {"workload": "BASELINE configs[2] on the other synthetic mesh SURVEY names: small_bunny.obj midpoint-subdivided twice (79 488 "
                               "triangles) on a 641 x 16 ground grid (20 512) = %d triangles, no pole; triangle list, reference camera"
                               % scene_b.n_triangles,
@@ -335,14 +337,7 @@ def main():
         api.create_BVHfromList(scene, st_b)
         build_s = time.perf_counter() - t1
         buf = torch.empty(NX * NY * 3, dtype=torch.float32, device="cuda")
-        for _ in range(3):
-            api.render_rows(scene, camera, st_b, NX, NY, args.spp, 0, NY, buf, stream=stream, bvh=True)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            api.render_rows(scene, camera, st_b, NX, NY, args.spp, 0, NY, buf, stream=stream, bvh=True)
-        torch.cuda.synchronize()
-        ms_b = (time.perf_counter() - t1) / 10 * 1e3
+        ms_b = timed_frames(lambda: api.render_rows(scene, camera, st_b, NX, NY, args.spp, 0, NY, buf, stream=stream, bvh=True), 20)
         bvh_world = {"what": "same frame, world = BVHNode tree (crt_render_rows_bvh): tiled kernels + chain of boxes per winner",
                      "parity": "tree shape pinned against rocThrust's thrust::sort run inside one device thread; AABB::hit, box arithmetic and "
                                "the triangle test pinned against the reference's own headers on this GPU (tests/test_ref_thrust.py, "
@@ -362,14 +357,8 @@ def main():
         scene_f.set_materials(mats, (np.arange(scene_f.n_triangles) // 2500 % 4).astype(np.int32))
         buf = torch.empty(NX * NY * 3, dtype=torch.float32, device="cuda")
         f_spp, f_depth = 4, 8
-        for _ in range(2):
-            api.render_rows_ex(scene_f, camera, st_f, NX, NY, f_spp, 0, NY, buf, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=f_depth, stream=stream)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            api.render_rows_ex(scene_f, camera, st_f, NX, NY, f_spp, 0, NY, buf, world=api.WORLD_BVH, shader=api.SHADER_SHADE, max_depth=f_depth, stream=stream)
-        torch.cuda.synchronize()
-        ms_f = (time.perf_counter() - t1) / 5 * 1e3
+        ms_f = timed_frames(lambda: api.render_rows_ex(scene_f, camera, st_f, NX, NY, f_spp, 0, NY, buf, world=api.WORLD_BVH, shader=api.SHADER_SHADE,
+                                                       max_depth=f_depth, stream=stream), 10)
         f2_shade = {"what": "recursive shade, depth %d, 4 material classes in bands, BVH world, %d spp, same mesh and camera: render_generic_kernel "
                             "(persistent wavefronts, pair walk shared by the wavefront)" % (f_depth, f_spp),
                     "parity": "PARITY UNPINNED (in-repo oracle; pow(x, 5.0f) and the tree's shape by stated rules)",

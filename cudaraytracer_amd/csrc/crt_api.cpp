@@ -973,6 +973,19 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
     p.rnx = 1.0f / (float)nx;
     p.rny = 1.0f / (float)ny;
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
+    {
+        float mag = 0.0f;   // the order the kernel summed them in (any order would do: the value feeds a conservative guard only)
+        for (int k = 0; k < 3; ++k) mag += fabsf(p.cam.llc[k]) + fabsf(p.cam.horizontal[k]) + fabsf(p.cam.vertical[k]) + fabsf(p.cam.origin[k]);
+        p.cam_mag = mag;
+        p.cam_thr = mag * 9.5367431640625e-7f;   // 2^-20 mag
+        // camera-only terms of per-tile computations (pixel_half_extents, tile_cone), in the kernels' own float expressions
+        p.pix_hu = (0.5f * p.rnx) * 1.00001f + 4.0e-7f + p.pos_du;
+        p.pix_hv = (0.5f * p.rny) * 1.00001f + 4.0e-7f + p.pos_dv;
+        float h2 = 0.0f, w2 = 0.0f;
+        for (int k = 0; k < 3; ++k) { h2 += p.cam.horizontal[k] * p.cam.horizontal[k]; w2 += p.cam.vertical[k] * p.cam.vertical[k]; }
+        p.cam_hlen = sqrtf(h2);
+        p.cam_vlen = sqrtf(w2);
+    }
 
     // BVH world, LambertShade on one Lambertian, where the tiled kernels do not apply (more than 2^22 triangles; a camera outside
     // the binning's range) or variant 1 asks for a per-ray walk: the generic kernel's walk shared by the wavefront is twice as
@@ -1085,6 +1098,19 @@ int crt_debug_audit_tiles(const crt_scene* scene, const crt_camera* camera, int 
     p.rnx = 1.0f / (float)nx;
     p.rny = 1.0f / (float)ny;
     p.pos_du = pos_du; p.pos_dv = pos_dv; p.K_slack = k_slack;
+    {
+        float mag = 0.0f;   // the order the kernel summed them in (any order would do: the value feeds a conservative guard only)
+        for (int k = 0; k < 3; ++k) mag += fabsf(p.cam.llc[k]) + fabsf(p.cam.horizontal[k]) + fabsf(p.cam.vertical[k]) + fabsf(p.cam.origin[k]);
+        p.cam_mag = mag;
+        p.cam_thr = mag * 9.5367431640625e-7f;   // 2^-20 mag
+        // camera-only terms of per-tile computations (pixel_half_extents, tile_cone), in the kernels' own float expressions
+        p.pix_hu = (0.5f * p.rnx) * 1.00001f + 4.0e-7f + p.pos_du;
+        p.pix_hv = (0.5f * p.rny) * 1.00001f + 4.0e-7f + p.pos_dv;
+        float h2 = 0.0f, w2 = 0.0f;
+        for (int k = 0; k < 3; ++k) { h2 += p.cam.horizontal[k] * p.cam.horizontal[k]; w2 += p.cam.vertical[k] * p.cam.vertical[k]; }
+        p.cam_hlen = sqrtf(h2);
+        p.cam_vlen = sqrtf(w2);
+    }
     unsigned long long* d = nullptr;
     int device = 0;
     Context* cxp = (hipGetDevice(&device) == hipSuccess) ? context_for(device, nullptr) : nullptr;

@@ -517,7 +517,7 @@ __device__ __forceinline__ TileCone tile_cone(const RenderParams& p, int x0, int
     const CameraPOD& c = p.cam;
     const float u0 = ((float)x0 - 1.0f) * p.rnx - p.pos_du, u1 = ((float)x0 + 9.0f) * p.rnx + p.pos_du;
     const float v0 = ((float)y0_global - 1.0f) * p.rny - p.pos_dv, v1 = ((float)y0_global + 9.0f) * p.rny + p.pos_dv;
-    float lo[3], hi[3], mag = 0.0f, len_hi = 0.0f;
+    float lo[3], hi[3], len_hi = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }
 #pragma unroll
@@ -535,17 +535,13 @@ __device__ __forceinline__ TileCone tile_cone(const RenderParams& p, int x0, int
     }
     float dc[3], lc2 = 0.0f, var = 0.0f;   // |d0| >= |d0(centre)| - (half extent of the affine map)
     const float uc = 0.5f * (u0 + u1), vc = 0.5f * (v0 + v1), hu = 0.5f * (u1 - u0), hv = 0.5f * (v1 - v0);
-    float h2 = 0.0f, w2 = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         dc[a] = ((c.llc[a] + uc * c.horizontal[a]) + vc * c.vertical[a]) - c.origin[a];
         lc2 += dc[a] * dc[a];
-        h2 += c.horizontal[a] * c.horizontal[a];
-        w2 += c.vertical[a] * c.vertical[a];
-        mag += fabsf(c.llc[a]) + fabsf(c.horizontal[a]) + fabsf(c.vertical[a]) + fabsf(c.origin[a]);
     }
-    var = hu * sqrtf(h2) + hv * sqrtf(w2);
-    const float eps = mag * 9.5367431640625e-7f;                     // 2^-20 mag: float evaluation of d0
+    var = hu * p.cam_hlen + hv * p.cam_vlen;                         // |horizontal|, |vertical|: camera-only, formed on the host
+    const float eps = p.cam_thr;                                     // 2^-20 mag: float evaluation of d0 (host)
     const float len_lo = (sqrtf(lc2) - var) * 0.99999f - 2.0f * eps;
     len_hi = len_hi * 1.00001f + 2.0f * eps;
     TileCone t;

@@ -57,6 +57,10 @@ struct RenderParams {
     float rnx, rny;              // 1.0f / float(nx), 1.0f / float(ny) (host, IEEE)
     float pos_du, pos_dv;        // tiled variant: position slack of the camera in (u,v) (host, camera_slacks)
     float K_slack;               // tiled variant: slack factor of the form values, whole screen (host, camera_slacks)
+    float pix_hu, pix_hv;        // half extents of a 1-pixel cell in (u, v) incl. position slack (pixel_half_extents; host)
+    float cam_hlen, cam_vlen;    // |horizontal|, |vertical| as tile_cone forms them (host)
+    float cam_mag, cam_thr;      // sum of |component| over llc, horizontal, vertical, origin, and 2^-20 of it (host; the sky loop's range
+                                 // guard: computed in the kernel they were loop invariants that hipcc hoisted to the entry and spilled)
 };
 
 __host__ __device__ inline int global_row(int row_begin, int strip_rows, int strip_step, int ly) {

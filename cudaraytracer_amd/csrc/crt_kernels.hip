@@ -544,6 +544,14 @@ __device__ __forceinline__ void exact_test_vec(const RecV& rc, int i_raw, V3 d, 
 // A wave-uniform float in a VGPR.  On gfx950 a VALU instruction with an SGPR source issues at half the
 // rate of a VGPR-only one (profiles/r1_ubench_valu2.txt: 4.1 vs 2.3 cycles per wave64 instruction);
 // the empty asm hides the value's origin, so hipcc keeps using the register copy inside the loop.
+// (float)n of a wave-uniform int, converted INSIDE the opaque instruction: written as in_vgpr((float)n) the conversion is a loop
+// invariant of its own that hipcc hoists to the kernel's entry and — at six waves per SIMD — spills (two of the list kernel's six
+// scratch slots were (float)nx and (float)ny).
+__device__ __forceinline__ float in_vgpr_from_int(int n) {
+    float v;
+    asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(v) : "s"(n));
+    return v;
+}
 __device__ __forceinline__ float in_vgpr(float x) {
     float v;
     asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
@@ -588,7 +596,7 @@ __device__ __forceinline__ void render_pixel(const RenderParams& p, int x, int l
 #define CRT_VGPR_CAM 1   // measured on the bench frame: shade 0.816 -> 0.769 ms (profiles/r2_tiled/sweep_occ.txt)
 #endif
     const bool kVgprCam = FASTDIV && CRT_VGPR_CAM && WANT_D2;   // ray set-up constants in VGPRs (see in_vgpr); not in the BVH mode (WANT_D2 false), whose kernel is short of registers as it is
-    const float fnx = kVgprCam ? in_vgpr((float)p.nx) : (float)p.nx, fny = kVgprCam ? in_vgpr((float)p.ny) : (float)p.ny;
+    const float fnx = kVgprCam ? in_vgpr_from_int(p.nx) : (float)p.nx, fny = kVgprCam ? in_vgpr_from_int(p.ny) : (float)p.ny;
     const float rnx = kVgprCam ? in_vgpr(p.rnx) : p.rnx, rny = kVgprCam ? in_vgpr(p.rny) : p.rny;
     CameraPOD cv = c;
     if (kVgprCam) {
@@ -760,7 +768,7 @@ __device__ __forceinline__ void render_sky_pixel_impl(const RenderParams& p, int
     const float hx = in_vgpr(c.horizontal[0]), hy = in_vgpr(c.horizontal[1]), hz = in_vgpr(c.horizontal[2]);
     const float vx = in_vgpr(c.vertical[0]), vy = in_vgpr(c.vertical[1]), vz = in_vgpr(c.vertical[2]);
     const float ox = in_vgpr(c.origin[0]), oy = in_vgpr(c.origin[1]), oz = in_vgpr(c.origin[2]);
-    const float fnx = in_vgpr((float)p.nx), fny = in_vgpr((float)p.ny), rnx = in_vgpr(p.rnx), rny = in_vgpr(p.rny);
+    const float fnx = in_vgpr_from_int(p.nx), fny = in_vgpr_from_int(p.ny), rnx = in_vgpr(p.rnx), rny = in_vgpr(p.rny);
     const float fx = (float)x, fy = (float)y;
     // can some ray of this wavefront's tile have |d0.y| < 2^-30 or a huge length?  (u, v) of the tile lie in
     // [x0/nx, (x0+8)/nx] x [y0/ny, (y0+8)/ny] up to rounding; a margin of one pixel each way covers that.
@@ -768,7 +776,7 @@ __device__ __forceinline__ void render_sky_pixel_impl(const RenderParams& p, int
     {
         const float u0 = ((float)(x & ~7) - 1.0f) * p.rnx, u1 = ((float)(x & ~7) + 9.0f) * p.rnx;
         const float v0 = ((float)(y & ~7) - 1.0f) * p.rny, v1 = ((float)(y & ~7) + 9.0f) * p.rny;
-        float lo = 3.0e38f, hi = -3.0e38f, mag = 0.0f;
+        float lo = 3.0e38f, hi = -3.0e38f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float uu = (k & 1) ? u1 : u0, vv = (k & 2) ? v1 : v0;
@@ -776,12 +784,11 @@ __device__ __forceinline__ void render_sky_pixel_impl(const RenderParams& p, int
             lo = fminf(lo, dy);
             hi = fmaxf(hi, dy);
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) mag += fabsf(c.llc[k]) + fabsf(c.horizontal[k]) + fabsf(c.vertical[k]) + fabsf(c.origin[k]);
+        const float mag = p.cam_mag;   // sum of |component| over llc, horizontal, vertical, origin (host)
         // safe: over the tile d0.y keeps one sign with |d0.y| >= 2^-20 mag at the corners; the float evaluation here and
         // per sample is within 2^-22 mag of the affine model each, so every sample has |d0.y| >= 2^-21 mag >= 2^-39,
         // and |d0| <= sqrt(3) mag < 2^40: the conditions unit_vector_fast_y votes on hold for all of them
-        const float thr = mag * 9.5367431640625e-7f;   // 2^-20 mag
+        const float thr = p.cam_thr;   // 2^-20 mag (host)
         const bool safe = mag < 274877906944.0f && thr >= 3.637978807091713e-12f && ((lo > 0.0f && lo >= thr) || (hi < 0.0f && -hi >= thr));
         guard_needed = __builtin_amdgcn_ballot_w64(!safe) != 0ull;
     }
@@ -1296,8 +1303,8 @@ __device__ __forceinline__ float pixel_q(float K, float hu, float hv, float B, f
     return __builtin_fmaf(K, M, __builtin_fmaf(hv, fabsf(C), hu * fabsf(B)) * 1.0001f);
 }
 __device__ __forceinline__ void pixel_half_extents(const RenderParams& p, float& hu, float& hv) {
-    hu = (0.5f * p.rnx) * 1.00001f + 4.0e-7f + p.pos_du;
-    hv = (0.5f * p.rny) * 1.00001f + 4.0e-7f + p.pos_dv;
+    hu = p.pix_hu;   // (0.5f * p.rnx) * 1.00001f + 4.0e-7f + p.pos_du, formed on the host (crt_api.cpp): in the kernel it was a loop
+    hv = p.pix_hv;   // invariant hoisted to the entry and kept in (or spilled from) a VGPR
 }
 // The rectangle test on the pixel (x, y_global) from forms stored as (A, B, C, q); q4 = q of w.
 __device__ __forceinline__ bool pixel_may_hit(const RenderParams& p, float4 f0, float4 f1, float4 f2, float4 f3, float q4,
@@ -1619,7 +1626,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 #endif
     {
         unsigned item = blockIdx.x;
+        const int lane_h = lane;
         while (item < total_heavy) {
+            int lane = lane_h;   // opaque per-item copy (see the light loop): LDS addresses are formed per item, not hoisted and spilled
+            asm volatile("" : "+v"(lane));
             int c = 0;
             unsigned idx = item;
             for (; c < kHeavyClasses - 1; ++c) {
@@ -1963,7 +1973,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     const unsigned kLightGroup = FULL ? 4u : max(1u, (split_packed >> 27) & 7u);
     const unsigned n_groups = (n_light + kLightGroup - 1) / kLightGroup;
     int chunk = (int)((blockIdx.x * WAVES + wave) % kLightChunks);
+    const int lane_k = lane;
     while (true) {
+        // an opaque per-iteration copy of the lane id: LDS addresses formed from it cannot be hoisted out of the tile loop, where at
+        // six waves per SIMD they were spilled to scratch (one v_mov per tile instead of a scratch reload per use)
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
         const unsigned c_len = ((n_groups + (unsigned)(kLightChunks - 1 - chunk)) / kLightChunks) * kLightGroup;   // positions of this chunk
         unsigned pos = 0xffffffffu;
         if (c_len != 0u) {
@@ -2294,6 +2309,7 @@ cls_prepass_kernel(const float* __restrict__ rec_in, const float* __restrict__ b
     if (FUSED) {
         float4 r4[4];
         derive_record(base + (size_t)i * kBaseFloats, cam.origin[0], cam.origin[1], cam.origin[2], r4);
+        // (always stored: the overflow fallbacks — a tile without a list walks ALL triangles — and the tree walks read any record)
         float4* o = reinterpret_cast<float4*>(rec_out + (size_t)i * kRecFloats);
         o[0] = r4[0]; o[1] = r4[1]; o[2] = r4[2]; o[3] = r4[3];
         r[0] = r4[0].x; r[1] = r4[0].y; r[2] = r4[0].z; r[3] = r4[0].w; r[4] = r4[1].x; r[5] = r4[1].y; r[6] = r4[1].z; r[7] = r4[1].w;
@@ -2336,16 +2352,47 @@ cls_prepass_kernel(const float* __restrict__ rec_in, const float* __restrict__ b
     float M[5] = {n1 * 1.001f, Ma, s1 * e21 * 1.001f + Ma * 9.5367431640625e-7f, q1 * 1.001f + Ma * 9.5367431640625e-7f, 0.0f};
     float4 rec4[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        rec4[k] = make_float4((float)FA[k], (float)FB[k], (float)FC[k], M[k]);
-        cls[(size_t)k * n_pad + i] = rec4[k];
-    }
+    for (int k = 0; k < 4; ++k) rec4[k] = make_float4((float)FA[k], (float)FB[k], (float)FC[k], M[k]);
     // w exactly as the binning kernel forms it (from the rounded records), so that both tests
     // bound the same function
     FA[4] = (double)(rec4[1].x - rec4[2].x - rec4[3].x);
     FB[4] = (double)(rec4[1].y - rec4[2].y - rec4[3].y);
     FC[4] = (double)(rec4[1].z - rec4[2].z - rec4[3].z);
     M[4] = M[2] + M[3] + 1.25f * M[1];
+
+    // A rank of a multi-GPU split renders strips of rows dealt round-robin (strip_step > 1): its rows cover the whole height of
+    // the screen, so the corner test below never culls by position, and every rank would clip every visible triangle (C5 at
+    // W = 8: the replicated prepass was most of T_bin).  Before the fp64 clipping: the binning's own conservative cell test
+    // (cell_may_hit on the fp32 forms, the cell = one full-width strip with the position slack and the rounding pads of
+    // bin_tri_kernel's cells) on each of the launch's strips; a triangle no ray of any of them can hit gets the empty box.
+    if (p.strip_step > 1) {
+        const float hu = 0.5f * 1.00001f + 4.0e-7f + p.pos_du;
+        float fa[5], fb[5], fc[5], qu[5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { fa[k] = rec4[k].x; fb[k] = rec4[k].y; fc[k] = rec4[k].z; }
+        fa[4] = rec4[1].x - rec4[2].x - rec4[3].x; fb[4] = rec4[1].y - rec4[2].y - rec4[3].y; fc[4] = rec4[1].z - rec4[2].z - rec4[3].z;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) qu[k] = hu * fabsf(fb[k]);
+        bool any = false;
+        const int n_strips = (p.row_count + p.strip_rows - 1) / p.strip_rows;
+        for (int s = 0; s < n_strips && !any; ++s) {
+            const int g0 = global_row(p.row_begin, p.strip_rows, p.strip_step, s * p.strip_rows);
+            const int rows = min(p.strip_rows, p.row_count - s * p.strip_rows);
+            const float vc = ((float)g0 + 0.5f * (float)rows) * p.rny;
+            const float hv = (0.5f * (float)rows * p.rny) * 1.00001f + 4.0e-7f + p.pos_dv;
+            float c[5], q[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                c[k] = __builtin_fmaf(0.5f, fb[k], __builtin_fmaf(vc, fc[k], fa[k]));
+                q[k] = __builtin_fmaf(p.K_slack, M[k], __builtin_fmaf(hv, fabsf(fc[k]), qu[k]) * 1.0001f);
+            }
+            any = cell_may_hit(c, q);   // (NaN anywhere: true)
+        }
+        if (!any) {   // the empty box alone: 16 B instead of 80 B of forms nobody would read
+            cls[(size_t)4 * n_pad + i] = make_float4(1.0e30f, -1.0e30f, 1.0e30f, -1.0e30f);
+            return;
+        }
+    }
 
     // Bounding box in (u,v) of every model position whose ray may be accepted: the screen
     // rectangle (widened by the position slack) clipped by the relaxed predicates
@@ -2412,6 +2459,9 @@ cls_prepass_kernel(const float* __restrict__ rec_in, const float* __restrict__ b
     cls[(size_t)4 * n_pad + i] = empty ? make_float4(1.0e30f, -1.0e30f, 1.0e30f, -1.0e30f)
                                        : make_float4((float)bu_lo - 2.0e-6f, (float)bu_hi + 2.0e-6f,
                                                      (float)bv_lo - 2.0e-6f, (float)bv_hi + 2.0e-6f);
+    if (empty) return;   // back-facing or off the screen for every ray: the binning selects by the box first, nothing reads its forms
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cls[(size_t)k * n_pad + i] = rec4[k];
 }
 
 hipError_t launch_cls_prepass(const float* d_rec, int n_tris, int n_pad, const RenderParams& p,

@@ -242,6 +242,116 @@ __device__ __forceinline__ bool bvh_walk_coop(const BvhView& b, const float* __r
     return ok;
 }
 
+// ---- ONE ray whose direction chain has not settled, walked by the whole wavefront ------------------------------------
+// 0.1 % of scattered rays have a chain that is neither fixed by c4 nor the 2-cycle (c3, c4): the element a node sees then
+// depends on its depth beyond what an item's class says, and rounds 2-3 walked such a ray ALONE over the skip links (the
+// literal loop: ~200 dependent node loads with 63 lanes idle, about 0.2 ms per ray — 30 % of the `shade` frame, measured by
+// walking them as if settled: 5.7 -> 4.0 ms).  Here the wavefront walks that ray level by level: all items of a round are
+// pair records of the SAME depth L, so their boxes see c_(L+2) and the triangles of their leaf children c_(L+4) — wave-
+// uniform directions, advanced by one normalisation per level (chain_at's mode 2: F iterated from c4; on ordinary
+// components unit_vector_fast and the skipped rotate(., 0) are the literal results bit for bit).  Same visited set, same
+// tests and the same merge key as every other walk.  o, c1..c4 are wave-uniform (broadcast from the ray's lane).
+// Returns false (nothing changed) when a level does not fit the lists or an element leaves the ordinary range: the
+// caller then walks the ray the literal way.
+template <bool PRIMARY>
+__device__ __forceinline__ bool bvh_walk_one(const BvhView& b, const float* __restrict__ rec, V3 o, V3 c1, V3 c2, V3 c3, V3 c4,
+                                             const CoopLds& L, float& t_out, int& slot_out, V3& dir_out) {
+    const unsigned lane = lanes_below(~0ull);
+    t_out = FLT_MAX;
+    slot_out = -1;
+    dir_out = c3;
+    {
+        const float4 n0 = b.nodes[0], n1 = b.nodes[1];
+        if (((__float_as_int(n1.w) >> 24) & 3) != 0) return false;   // a one-leaf tree has no pair records
+        const V3 y1 = V3{reciprocal<true>(c1.x), reciprocal<true>(c1.y), reciprocal<true>(c1.z)};
+        if (!box_hit_fast(n0, n1, o, c1, y1)) return true;            // the root's box sees c1: a miss
+    }
+    const unsigned half = (unsigned)L.cap / 2u;                       // two lists of pair indices: this level's and the next one's
+    V3 dB = c2, dMid = c3, dT = c4;                                   // the window c_(L+2), c_(L+3), c_(L+4) at L = 0
+    unsigned cur = 0u, n_cur = 1u;
+    if (lane == 0u) L.nodes[0] = 0u;
+    unsigned long long my_key = ~0ull;                                // this lane's best hit so far
+    float my_t = FLT_MAX;
+    int my_slot = -1;
+    V3 my_dir = c3;
+    coop_sync();
+    bool ok = true;
+    while (n_cur != 0u) {
+        const V3 yB = V3{reciprocal<true>(dB.x), reciprocal<true>(dB.y), reciprocal<true>(dB.z)};
+        unsigned n_next = 0u, nt = 0u;
+        for (unsigned base = 0u; base < n_cur; base += 64u) {
+            const bool has = base + lane < n_cur;
+            const unsigned pair = has ? L.nodes[cur * half + base + lane] : 0u;
+            walk_stat(b, 2, __builtin_amdgcn_ballot_w64(has));
+            const PairStep s = pair_eval(pair_load(b, pair), has, o, dB, yB, dT);
+            if (n_next + 128u > half || nt + 256u > (unsigned)kCoopTriCap) { ok = false; break; }
+            const unsigned long long ml = __builtin_amdgcn_ballot_w64(s.go_l), mr = __builtin_amdgcn_ballot_w64(s.go_r);
+            unsigned* next = L.nodes + (cur ^ 1u) * half;
+            if (s.go_r) next[n_next + lanes_below(mr)] = (unsigned)s.ref_r;
+            const unsigned nr = (unsigned)__builtin_popcountll(mr);
+            if (s.go_l) next[n_next + nr + lanes_below(ml)] = (unsigned)s.ref_l;
+            n_next += nr + (unsigned)__builtin_popcountll(ml);
+            const int c = s.cnt_l + s.cnt_r;   // 0..4 triangles of hit leaf children
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64((c & 1) != 0), b1 = __builtin_amdgcn_ballot_w64((c & 2) != 0),
+                                     b2 = __builtin_amdgcn_ballot_w64((c & 4) != 0);
+            unsigned at = nt + lanes_below(b0) + 2u * lanes_below(b1) + 4u * lanes_below(b2);
+            if (s.cnt_l >= 1) L.tris[at++] = (s.cnt_l == 2 ? 1u << 23 : 0u) | (unsigned)(s.ref_l & 0x7fffff);
+            if (s.cnt_l == 2) L.tris[at++] = (2u << 23) | (unsigned)((s.ref_l & 0x7fffff) + 1);
+            if (s.cnt_r >= 1) L.tris[at++] = (s.cnt_r == 2 ? 1u << 23 : 0u) | (unsigned)(s.ref_r & 0x7fffff);
+            if (s.cnt_r == 2) L.tris[at++] = (2u << 23) | (unsigned)((s.ref_r & 0x7fffff) + 1);
+            nt += (unsigned)__builtin_popcountll(b0) + 2u * (unsigned)__builtin_popcountll(b1) + 4u * (unsigned)__builtin_popcountll(b2);
+        }
+        if (!ok) break;
+        coop_sync();
+        for (unsigned base = 0u; base < nt; base += 64u) {            // this level's leaf children: their triangles see c_(L+4)
+            walk_stat(b, 4, __builtin_amdgcn_ballot_w64(base + lane < nt));
+            if (base + lane < nt) {
+                const unsigned item = L.tris[base + lane], slot = item & 0x7fffffu, place = (item >> 23) & 3u;
+                float t;
+                if (tri_hit_lane<true, PRIMARY>(rec, (int)slot, o, dT, t) && t < FLT_MAX) {   // hitable_list.h:84 against t_max = FLT_MAX
+                    const unsigned partner = place == 0u ? slot : (place == 1u ? slot + 1u : slot - 1u);
+                    const unsigned long long key = hit_key(t, (int)(((0xffffffu - partner) << 3) | (place << 1)));
+                    if (key < my_key) { my_key = key; my_t = t; my_slot = (int)slot; my_dir = dT; }
+                }
+            }
+        }
+        // the next level: c_(L+5) = F(c_(L+4)); every element must stay ordinary (it moves by ulps: it does)
+        dB = dMid;
+        dMid = dT;
+        dT = chain_next<true>(b.rot, dT);
+        if (!(fminf(fminf(fabsf(dT.x), fabsf(dT.y)), fabsf(dT.z)) >= 9.094947017729282e-13f)) { ok = false; break; }
+        cur ^= 1u;
+        n_cur = n_next;
+        coop_sync();
+    }
+    coop_sync();
+    if (!ok) return false;
+    // the ray's winner: the smallest key over the lanes; its raw t and direction from the lane that found it
+    if (lane == 0u) L.best[0] = ~0ull;
+    coop_sync();
+    if (my_key != ~0ull) atomicMin(&L.best[0], my_key);
+    coop_sync();
+    const unsigned long long kmin = L.best[0];
+    if (kmin != ~0ull && my_key == kmin) {   // (keys are unique per triangle)
+        L.rays[0] = make_float4(my_t, __int_as_float(my_slot), my_dir.x, my_dir.y);
+        L.rays[1] = make_float4(my_dir.z, 0.0f, 0.0f, 0.0f);
+    }
+    coop_sync();
+    if (kmin != ~0ull) {
+        const float4 r0 = L.rays[0], r1 = L.rays[1];
+        t_out = r0.x;
+        slot_out = __float_as_int(r0.y);
+        dir_out = V3{r0.z, r0.w, r1.x};
+    }
+    coop_sync();
+    return true;
+}
+
+__device__ __forceinline__ V3 bcast3(V3 v, int src) {   // lane src's vector, wave-uniform
+    return V3{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), src)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), src)),
+              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), src))};
+}
+
 // bvh_trace (crt_bvh_kernels.hpp) for the shared walk: called by all lanes; `active`: this lane has a ray.
 template <bool FAST>
 __device__ __forceinline__ void bvh_trace_coop(const BvhView& b, const float* __restrict__ rec, V3 o, V3 d1, int force_mode, bool active,
@@ -278,7 +388,22 @@ __device__ __forceinline__ void bvh_trace_coop(const BvhView& b, const float* __
     pd.cyc = mode == 1;
     bool take = active && ordinary && mode != 2;
     if (!bvh_walk_coop<false>(b, rec, o, c1, pd, take, L, best_t, best_slot, dir_used)) take = false;   // list full: nobody has a result
-    if (__builtin_amdgcn_ballot_w64(active && !take) != 0ull) {   // the few lanes the pair walk cannot serve: alone, the literal way
+    // rays with ordinary components whose chain has not settled (mode 2): one at a time, the whole wavefront on each (bvh_walk_one)
+    for (unsigned long long irr = __builtin_amdgcn_ballot_w64(active && ordinary && mode == 2); irr != 0ull; irr &= irr - 1ull) {
+        const int src = (int)__builtin_ctzll(irr);
+        float t1;
+        int s1;
+        V3 d1u;
+        if (bvh_walk_one<false>(b, rec, bcast3(o, src), bcast3(c1, src), bcast3(c2, src), bcast3(c3, src), bcast3(c4, src), L, t1, s1, d1u)) {
+            if ((int)lanes_below(~0ull) == src) {
+                best_t = t1;
+                best_slot = s1;
+                dir_used = d1u;
+                take = true;
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(active && !take) != 0ull) {   // what is left (non-ordinary components, lists that ran full): alone, the literal way
         if (active && !take) bvh_walk_general<FAST, false>(b, rec, o, c1, c2, c3, c4, mode, best_t, best_slot, dir_used);
     }
 }
