@@ -2360,40 +2360,9 @@ cls_prepass_kernel(const float* __restrict__ rec_in, const float* __restrict__ b
     FC[4] = (double)(rec4[1].z - rec4[2].z - rec4[3].z);
     M[4] = M[2] + M[3] + 1.25f * M[1];
 
-    // A rank of a multi-GPU split renders strips of rows dealt round-robin (strip_step > 1): its rows cover the whole height of
-    // the screen, so the corner test below never culls by position, and every rank would clip every visible triangle (C5 at
-    // W = 8: the replicated prepass was most of T_bin).  Before the fp64 clipping: the binning's own conservative cell test
-    // (cell_may_hit on the fp32 forms, the cell = one full-width strip with the position slack and the rounding pads of
-    // bin_tri_kernel's cells) on each of the launch's strips; a triangle no ray of any of them can hit gets the empty box.
-    if (p.strip_step > 1) {
-        const float hu = 0.5f * 1.00001f + 4.0e-7f + p.pos_du;
-        float fa[5], fb[5], fc[5], qu[5];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { fa[k] = rec4[k].x; fb[k] = rec4[k].y; fc[k] = rec4[k].z; }
-        fa[4] = rec4[1].x - rec4[2].x - rec4[3].x; fb[4] = rec4[1].y - rec4[2].y - rec4[3].y; fc[4] = rec4[1].z - rec4[2].z - rec4[3].z;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) qu[k] = hu * fabsf(fb[k]);
-        bool any = false;
-        const int n_strips = (p.row_count + p.strip_rows - 1) / p.strip_rows;
-        for (int s = 0; s < n_strips && !any; ++s) {
-            const int g0 = global_row(p.row_begin, p.strip_rows, p.strip_step, s * p.strip_rows);
-            const int rows = min(p.strip_rows, p.row_count - s * p.strip_rows);
-            const float vc = ((float)g0 + 0.5f * (float)rows) * p.rny;
-            const float hv = (0.5f * (float)rows * p.rny) * 1.00001f + 4.0e-7f + p.pos_dv;
-            float c[5], q[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                c[k] = __builtin_fmaf(0.5f, fb[k], __builtin_fmaf(vc, fc[k], fa[k]));
-                q[k] = __builtin_fmaf(p.K_slack, M[k], __builtin_fmaf(hv, fabsf(fc[k]), qu[k]) * 1.0001f);
-            }
-            any = cell_may_hit(c, q);   // (NaN anywhere: true)
-        }
-        if (!any) {   // the empty box alone: 16 B instead of 80 B of forms nobody would read
-            cls[(size_t)4 * n_pad + i] = make_float4(1.0e30f, -1.0e30f, 1.0e30f, -1.0e30f);
-            return;
-        }
-    }
-
+    // (Round 4, measured and dropped: for a rank of a multi-GPU split, the binning's cell test on each full-width strip before the
+    // clipping — every edge line of a triangle crosses a 3 840-pixel-wide cell somewhere, so interval bounds per form exclude
+    // nothing; and clipping in a second kernel over a compacted list — 37 + 57 us against this kernel's 82 us at C5.)
     // Bounding box in (u,v) of every model position whose ray may be accepted: the screen
     // rectangle (widened by the position slack) clipped by the relaxed predicates
     //   dn >= -S_dn  and  [ a, su, dq, w >= -S   or   a, su, dq, w <= +S ],   S_X = K * M_X,

@@ -48,3 +48,18 @@ def gpu(crt_built):
                     "libamdhip64.so.7 before torch did (import torch before libcrt_hip.so or any other ROCm library; "
                     "cudaraytracer_amd/_lib.py, INTEGRATION.md \"One HIP runtime per process\")")
     return torch
+
+
+@pytest.fixture(scope="session")
+def c2_oracle_frame(oracle):
+    """BASELINE configs[1] (800x600, 16 spp, the 32-triangle Cornell box) through the CPU oracle, once per session: the frame
+    and the RNG states after it (d, v0..v4 per pixel).  Ten seconds of CPU that seven GPU tests used to spend each."""
+    import numpy as np
+    from cudaraytracer_amd import scenes
+    sc = scenes.cornell32()
+    nx, ny, spp = 800, 600, 16
+    c = sc["camera"]
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    ocam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
+    ref, states = oracle.render(w, ocam, nx, ny, spp)
+    return sc, nx, ny, spp, ref, np.concatenate([states["d"][:, None], states["v"]], axis=1)

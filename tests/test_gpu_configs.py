@@ -187,18 +187,13 @@ def test_c5_full_frame_64spp_audit_bands_and_crops(gpu, oracle, obj_dir):
         check_crop(oracle, w, ocam, full, nx, ny, spp, win)
 
 
-def test_c2_cornell_800x600x16_full_frame_against_the_oracle(gpu, oracle):
+def test_c2_cornell_800x600x16_full_frame_against_the_oracle(gpu, c2_oracle_frame):
     """BASELINE configs[1] at its own size: 800x600, 16 spp, the 32-triangle Cornell box.  The whole frame — pixels and
     RNG states — against the CPU oracle (7.7 M rays x 32 triangles), tiled and brute force."""
-    sc = scenes.cornell32()
-    nx, ny, spp = 800, 600, 16
+    sc, nx, ny, spp, ref, want_states = c2_oracle_frame
     scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
     c = sc["camera"]
     cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
-    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
-    ocam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
-    ref, states = oracle.render(w, ocam, nx, ny, spp)
-    want_states = np.concatenate([states["d"][:, None], states["v"]], axis=1)
     for variant in (2, 1):
         rgb, st = render(gpu, scene, cam, nx, ny, spp, variant=variant)
         assert np.array_equal(bits(rgb), bits(ref)), (variant, int((bits(rgb) != bits(ref)).any(axis=2).sum()))

@@ -302,14 +302,11 @@ def test_aperture_is_rejected(gpu):
 
 
 # ---------------------------------------------------------------- BASELINE sizes
-def test_c2_full_size_matches_oracle(gpu, oracle, variant):
-    """configs[1]: 800x600, 16 spp, Cornell-32 — the oracle needs ~20 s for the full frame."""
-    sc = scenes.cornell32()
-    nx, ny, spp = 800, 600, 16
+def test_c2_full_size_matches_oracle(gpu, c2_oracle_frame, variant):
+    """configs[1]: 800x600, 16 spp, Cornell-32 — the oracle's full frame (ten seconds of CPU) is rendered once per session."""
+    sc, nx, ny, spp, ref, _ = c2_oracle_frame
     scene, cam = make(sc, nx, ny)
     (rgb,), _ = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
-    w, ocam = oracle_pair(oracle, sc, nx, ny)
-    ref, _ = oracle.render(w, ocam, nx, ny, spp)
     assert np.array_equal(bits(rgb), bits(ref))
 
 

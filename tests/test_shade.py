@@ -413,3 +413,40 @@ def test_gpu_shade_random_soups_match_oracle(gpu, oracle, block):
         got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH if world == "bvh" else api.WORLD_LIST, shader, depth)
         assert same(got, ref), (seed, world, shader, depth, n)
         assert np.array_equal(st.export()[1:], after[1:]), (seed, world, shader, depth, n)
+
+
+@pytest.mark.gpu
+def test_gpu_shade_with_tiny_and_huge_stored_normals_matches_oracle(gpu, oracle):
+    """Stored normals of subnormal size: the reference's float dot(direction, normal) rounds to +-0, `< 0` is false and the
+    triangle IS tested (triangle.h:61) whatever the exact sign says — so the pair records' normal cones (built in double on
+    the host) must not cover such a triangle's subtree.  Same for normals near FLT_MAX (inf - inf = NaN in the float dot).
+    Every other triangle of the pile keeps an honest normal, so cones exist around the odd ones."""
+    rng = np.random.RandomState(77)
+    sc = scenes.random_soup(240, 77, extent=3.0, size=1.2, z_range=(-9.0, -3.0))
+    nrm = rng.normal(size=(240, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+    nrm[::3] *= np.float32(-1.0)
+    tiny, huge = np.arange(5, 240, 16), np.arange(11, 240, 32)
+    nrm[tiny] = (nrm[tiny].astype(np.float64) * 1e-42).astype(np.float32)          # subnormal components
+    nrm[huge] = (nrm[huge].astype(np.float64) * 3e38).astype(np.float32)
+    sc["normals"] = nrm
+    mats = [(api.LAMBERTIAN, (0.65, 0.05, 0.05), 0.0), (api.METAL, (0.8, 0.85, 0.88), 0.0), (api.DIELECTRIC, (1, 1, 1), 1.5)]
+    of = (np.arange(240) % 3).astype(np.int32)
+    nx, ny, spp, depth = 48, 32, 3, 6
+    c = sc["camera"]
+    w = oracle.World(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+    w.set_materials(mats, of)
+    ocam = oracle.make_camera(c["lookfrom"], c["lookat"], (0, 1, 0), c["vfov"], np.float32(nx) / np.float32(ny), c["aperture"], c["focus"])
+    states = oracle.fresh_states(nx, ny)
+    bvh = oracle.Bvh(w, states)
+    ref, states = oracle.render_ex(w, bvh, oracle.SHADER_SHADE, ocam, nx, ny, spp, states, max_depth=depth)
+    after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
+    for variant in (0, 11, 9):
+        scene = api.Scene.from_mesh(sc["points"], sc["idx"], sc["normals"], sc["index_base"])
+        cam = api.create_camera(nx, ny, c["lookfrom"], c["lookat"], c["focus"], c["aperture"], c["vfov"])
+        st = api.SetCurandState(nx, ny, 0)
+        api.create_BVHfromList(scene, st)
+        scene.set_materials(mats, of)
+        got = hip_render(gpu, scene, cam, st, nx, ny, spp, api.WORLD_BVH, api.SHADER_SHADE, depth, variant)
+        assert same(got, ref), variant
+        assert np.array_equal(st.export()[1:], after[1:]), variant
