@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4: the evidence set of the final kernels in one gpurun call: GPU suite, bench line, rocprofv3 trace + PMC passes of the
-# bench command and of the f-row workloads, configuration and strip times.  Summaries land under gpurun_out/r4_final/.
+# bench command and of the f-row workloads, configuration times (strip times: tools/strip_time.py, profiles/r4/strip_time_*.txt).  Summaries land under gpurun_out/r4_final/.
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$REPO"
@@ -12,6 +12,5 @@ bash tools/profile_bench.sh r4 > $O/profile_bench.log 2>&1 && bash tools/pmc_ext
 bash tools/r4_profile_f.sh > $O/profile_f.log 2>&1; echo "profile_f rc=$?"
 mkdir -p $O/f && for w in shade bvh_tiled; do cp gpurun_out/prof_r4_$w/pmc_summary.json $O/f/pmc_summary_$w.json; cp gpurun_out/prof_r4_$w/kernel_stats.csv $O/f/kernel_stats_$w.csv; done
 python tools/config_times.py > $O/config_times.txt 2>&1
-for f in C3 C4 C5; do for wld in list bvh; do python tools/strip_time.py $f 1,2,4,8 0 $wld 2>&1 | grep "W="; done; done > $O/strip_times.txt
 python tools/shade_time.py > $O/shade_time.txt 2>&1
 tail -3 $O/config_times.txt; tail -3 $O/shade_time.txt
