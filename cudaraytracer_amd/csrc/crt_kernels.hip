@@ -1522,6 +1522,83 @@ __device__ __forceinline__ void trace_pairs(Area& area, const int* ent, const un
     }
 }
 
+// ---- far pairs: the balanced walk for a slice of a shared tile that is LONGER than its staging area.  Rounds 1-3 staged the
+// first 64 entries and walked the rest with wave-uniform records — every lane tests every remaining entry whatever its pixel,
+// one scalar-memory round trip per entry: 46 entries cost a 768-entry tile 10 us per sample, 219 entries cost the ~1 980-entry
+// pole tiles of the C5 frame 45 us, and those 64-sample chains ended the launch (and every rank's share of it).  Instead the
+// wave classifies ALL entries of its slice against the pixels once per tile (same test as stage_candidates, forms read with
+// wave-uniform loads) and lays the surviving (pixel, entry) pairs out in its staging area as 16-bit words
+// pixel | position in the slice << 6 (the area holds 2 048 of them; a slice up to 1 024 entries); every sample then takes
+// ceil(pairs / 64) steps, each lane fetching ITS pair's pool word and record from global memory (L2 after the first sample) —
+// the pool word two steps ahead, the record one step ahead of the test.
+// Returns the number of pairs, or 0xffffffff when they do not fit `cap` words (the caller then stages as before).
+constexpr int kFarMaxSlice = 1024;
+__device__ __forceinline__ unsigned build_far_pairs(unsigned short* __restrict__ out, unsigned cap, const RenderParams& p,
+                                                    const float4* __restrict__ cls, int n_pad, const uint32_t* __restrict__ lst,
+                                                    int first, int step, int n, int lane, bool valid, int x, int y_global,
+                                                    bool count_all, unsigned& total_out) {
+    const unsigned long long lanemask_lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned total = 0;
+    for (int base = 0; base < n && (total <= cap || count_all); base += 64) {
+        const int m = min(64, n - base);
+        const unsigned mine = (lane < m) ? lst[first + (base + lane) * step] : 0u;
+#pragma unroll 2
+        for (int k = 0; k < m; ++k) {
+            const int t = __builtin_amdgcn_readlane((int)mine, k) & 0x7fffffff;
+            float4 f0 = cls[(size_t)0 * n_pad + t], f1 = cls[(size_t)1 * n_pad + t];
+            float4 f2 = cls[(size_t)2 * n_pad + t], f3 = cls[(size_t)3 * n_pad + t];
+            const float q4 = pixel_forms(p, f0, f1, f2, f3);
+            bool sure;
+            const bool may = pixel_may_hit(p, f0, f1, f2, f3, q4, x, y_global, sure) && valid;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(may);
+            const unsigned cnt = (unsigned)__builtin_popcountll(mask);
+            if (may && total + cnt <= cap)
+                out[total + (unsigned)__builtin_popcountll(mask & lanemask_lt)] = (unsigned short)((unsigned)lane | (unsigned)(base + k) << 6);
+            total += cnt;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    total_out = total;   // diagnostics (count_all: the whole slice is counted even when it does not fit)
+    return total <= cap ? total : 0xffffffffu;
+}
+
+__device__ __forceinline__ RecV load_rec_lane(const float* __restrict__ rec, unsigned t) {
+    const float4* r = reinterpret_cast<const float4*>(rec + (size_t)t * kRecFloats);
+    RecV rc;
+    rc.a = r[0]; rc.b = r[1]; rc.c = r[2]; rc.d = r[3];
+    return rc;
+}
+
+// One sample over the far pairs (n >= 1) of the slice lst[first + pos * step]: minima into keys[pixel].
+template <class RayOf>
+__device__ __forceinline__ void trace_far_pairs(const unsigned short* far, unsigned n, const float* __restrict__ rec,
+                                                const uint32_t* __restrict__ lst, int first, int step, int lane, RayOf ray_of,
+                                                unsigned long long* keys) {
+    const unsigned ln = (unsigned)lane;
+    unsigned w0 = far[ln < n ? ln : 0u], w1 = far[ln + 64u < n ? ln + 64u : 0u];
+    unsigned e0 = lst[first + (int)(w0 >> 6) * step], e1 = lst[first + (int)(w1 >> 6) * step];
+    RecV cur = load_rec_lane(rec, e0 & 0x7fffffffu);
+    for (unsigned base = 0; base < n; base += 64u) {
+        RecV nxt = cur;
+        unsigned w2 = w1, e2 = e1;
+        if (base + 64u < n) nxt = load_rec_lane(rec, e1 & 0x7fffffffu);   // in flight while this step's record is tested
+        if (base + 128u < n) {
+            w2 = far[base + 128u + ln < n ? base + 128u + ln : 0u];
+            e2 = lst[first + (int)(w2 >> 6) * step];
+        }
+        const int pix = (int)(w0 & 63u);
+        const V3 dp = ray_of(pix);
+        float t_pair = FLT_MAX;
+        int i_pair = -1;
+        exact_test_lane<true>(cur, (int)(e0 & 0x7fffffffu), (e0 & kCullSureBit) != 0u, base + ln < n, dp, t_pair, i_pair);
+        if (i_pair >= 0) atomicMin(&keys[pix], hit_key(t_pair, i_pair));
+        w0 = w1; e0 = e1; cur = nxt;
+        w1 = w2; e1 = e2;
+    }
+}
+
 // ---- shading kernel of the tiled variant.  Persistent blocks of WAVES wavefronts (exactly as
 // many blocks as are resident) take tiles from the work queues.  Heavy tiles (heaviest first;
 // block b starts with item b) are traced by all waves of a block together: wave 0 owns the
@@ -1682,7 +1759,20 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             // sample instead, whose candidate masks were 24 VGPRs live across the sample loop: most of that kernel's scratch).
             // Tiles without a list walk the tree, wave 0 alone.
             const bool tree_tile = BVH && (walk_all || !VREC);
-            const int n_lds = (VREC && !walk_all && !tree_tile) ? min(kStage, cnt_w) : 0;
+            // list world, a slice longer than the staging area: all of it as far pairs (build_far_pairs), nothing staged
+            unsigned n_far = 0xffffffffu, n_far_all = 0u;
+            if (!BVH && VREC && WAVES <= 8 && !walk_all && cnt_w > kStage && cnt_w <= kFarMaxSlice && dbg_pairs != 0)
+                n_far = build_far_pairs(reinterpret_cast<unsigned short*>(&lrec[wave]), (unsigned)(sizeof(Area) / sizeof(unsigned short)), p, cls, n_pad,
+                                        lst, swave, slice_waves, cnt_w, lane, lane_valid, x,
+                                        global_row(p.row_begin, p.strip_rows, p.strip_step, ly), stats != nullptr, n_far_all);
+            const bool far = n_far != 0xffffffffu;
+            if (stats && lane == 0 && !BVH && VREC && !walk_all && cnt_w > kStage) {   // slices as far pairs, their pairs, slices that did not fit, the most pairs of a slice
+                atomicAdd(&stats[43], far ? 1ull : 0ull);
+                atomicAdd(&stats[44], far ? (unsigned long long)n_far : 0ull);
+                atomicAdd(&stats[45], far ? 0ull : 1ull);
+                atomicMax(&stats[46], (unsigned long long)n_far_all);
+            }
+            const int n_lds = (VREC && !walk_all && !tree_tile && !far) ? min(kStage, cnt_w) : 0;
             int slice_mine = 0;
             Cand cand = {0u, 0u, 0u, 0u};
             if (n_lds > 0) {   // per-pixel candidates among the staged entries of this wave's slice
@@ -1746,6 +1836,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             }
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
+                if (!BVH && far) {
+                    if (n_far != 0u)
+                        trace_far_pairs(reinterpret_cast<const unsigned short*>(&lrec[wave]), n_far, rec, lst, swave, slice_waves, lane,
+                                        [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key);
+                    continue;
+                }
                 if (slice_pairs != 0xffffffffu)
                     trace_pairs(lrec[wave], lent[wave], lpairs[wave], slice_pairs, lane,
                                 [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key);

@@ -446,6 +446,36 @@ def test_tiled_equals_brute_force_with_shuffled_triangle_order(gpu, crt_built):
     assert n_pass > 0 and n_missing == 0 and n_cull == 0
 
 
+@pytest.mark.parametrize("n_lat,n_lon,nx,ny,fits", [(8, 3000, 320, 180, True), (6, 12000, 256, 144, False)])
+def test_pole_tiles_longer_than_the_staging_areas(gpu, crt_built, n_lat, n_lon, nx, ny, fits):
+    """A lat-long sphere with many meridians: the tiles at its poles hold thousands of entries, so the slices of the
+    waves that share them are longer than their 64-entry staging areas and go as far pairs (build_far_pairs: every
+    entry classified per pixel, records from global memory) — or, when the pairs do not fit a wave's area, staged +
+    wave-uniform walk as before.  Same pixels and RNG states as the brute force, also with the tiles dealt as row slabs."""
+    sc = scenes.displaced_sphere(n_lat, n_lon, amp=0.02)
+    spp = 6
+    scene, cam = make(sc, nx, ny)
+    outs = {}
+    for v in (1, 2, 10):
+        prev = crt_built.crt_set_kernel_variant(v)
+        try:
+            if v == 2:
+                api.tiled_stats(1)
+            (o,), st = hip_render_with_states(gpu, scene, cam, nx, ny, spp)
+            if v == 2:
+                stats = api.tiled_stats(0)
+        finally:
+            crt_built.crt_set_kernel_variant(prev)
+        outs[v] = (o, st)
+    for v in (2, 10):
+        assert np.array_equal(bits(outs[v][0]), bits(outs[1][0])), v
+        assert np.array_equal(outs[v][1], outs[1][1]), v
+    far_slices, far_pairs, overflowed = stats[43], stats[44], stats[45]
+    assert far_slices > 0 and far_pairs > 0 and (overflowed == 0) == fits, stats[43:46]
+    n_pass, n_missing, n_cull, _ = api.audit_tiles(scene, cam, nx, ny, 2)
+    assert n_pass > 0 and n_missing == 0 and n_cull == 0
+
+
 @pytest.mark.gpu
 def test_diagnostics_do_not_change_pixels(gpu, crt_built):
     """crt_debug_tiled_stats: neither the counters (mode 1) nor the wave timeline (mode 2) may touch

@@ -36,7 +36,8 @@ print("hist (bucket b: 2^(b-1) <= n < 2^b):", o[8:24])
 print("shade kernel cycles: heavy phase sum over blocks %d max %d | light phase sum over waves %d max %d | max wave total %d" % tuple(o[24:29]))
 print("bin busiest wavefront: regions %d, tiles box-tested %d, cycles %d" % tuple(o[29:32]))
 print("heavy tiles %d (sum survivors %d): master wave cycles per tile: setup+merge+shade %.0f, own trace %.0f, wait B2 %.0f" % (o[35], o[36], o[32]/max(o[35],1), o[33]/max(o[35],1), o[34]/max(o[35],1)))
-print("kernel ms", api.last_kernel_times())
+print("shared tiles' slices longer than a staging area: %d as far pairs (%d pairs), %d did not fit; most pairs of one slice %d" % tuple(o[43:47]))
+print("kernel ms", api.last_kernel_times(), flush=True)
 print("light tiles with geometry %d: list entries %.1f per tile; per-pixel candidates: longest of the wavefront %.1f, mean %.2f; pair buffer overflowed in %d tiles, %.0f pairs per tile otherwise"
       % (o[37], o[38] / max(o[37], 1), o[39] / max(o[37], 1), o[40] / max(o[37], 1) / 64.0, o[41], o[42] / max(o[37] - o[41], 1)))
 
