@@ -424,6 +424,18 @@ def sample_timeline():
     return np.ctypeslib.as_array(out).reshape(4, 256, 2).copy()
 
 
+def light_timeline():
+    """crt_debug_wave_timeline(-2): (8192, 2) per wavefront: start stamp of its last light tile with geometry;
+    tile | entries << 32 | such tiles taken << 48."""
+    import numpy as np
+    out = (C.c_uint64 * (3 * 8192))()
+    n = _lib.lib().crt_debug_wave_timeline(out, -2)
+    if n < 0:
+        check(n)
+    a = np.ctypeslib.as_array(out)
+    return np.concatenate([a[: 2 * 8192].reshape(8192, 2), a[2 * 8192:].reshape(8192, 1)], axis=1).copy()
+
+
 def audit_tiles(scene, camera, nx, ny, samples, seed=0):
     """crt_debug_audit_tiles: (passing pairs, pairs missing from a tile list, cull-sure violations, offender)."""
     out = (C.c_uint64 * 4)()

@@ -1164,13 +1164,18 @@ int crt_debug_wave_timeline(uint64_t* out, int max_waves) {
     // Timeline mode of crt_debug_tiled_stats: three 100 MHz time stamps (start, end of the shared-tile phase, end) and
     // (entries << 32 | tile) of the block's last shared tile per wavefront of the last shade_tiles_kernel launch,
     // 4 * max_waves words; returns the number of slots copied.
-    if (!out || (max_waves <= 0 && max_waves != -1)) return fail(CRT_ERR_INVALID, "crt_debug_wave_timeline: bad arguments");
+    if (!out || (max_waves <= 0 && max_waves != -1 && max_waves != -2)) return fail(CRT_ERR_INVALID, "crt_debug_wave_timeline: bad arguments");
     if (!g_d_stats) return fail(CRT_ERR_INVALID, "crt_debug_wave_timeline: stats are not enabled");
     if (max_waves == -1) {   // the per-sample log of the first blocks instead: 2 * kStatsSampleBlocks * kStatsSampleSlots words
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(out, g_d_stats + crt::kStatsSampleLog, (size_t)2 * crt::kStatsSampleBlocks * crt::kStatsSampleSlots * sizeof(uint64_t),
                           hipMemcpyDeviceToHost));
         return crt::kStatsSampleBlocks * crt::kStatsSampleSlots;
+    }
+    if (max_waves == -2) {   // per wavefront: its last light tile with geometry (start stamp; tile | entries << 32 | such tiles taken << 48)
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, g_d_stats + crt::kStatsLightLog, (size_t)3 * crt::kStatsWaveSlots * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        return crt::kStatsWaveSlots;
     }
     const int n = std::min(max_waves, crt::kStatsWaveSlots);
     HIP_TRY(hipDeviceSynchronize());

@@ -735,6 +735,84 @@ __device__ __forceinline__ int tile_reference_path(const BvhTiles& bt, int slot0
     return first;
 }
 
+// ---- the chain of boxes of a winner on the hot chain, without walking it (round 4) ------------------------------------
+// AABB::hit (aabb.h:30-42) per axis: q(face) = fl(fl(face - o) / d), t0 = ffmin(q(min), q(max)), t1 = ffmax(..); t_min = ffmax(t0,
+// t_min); t_max = ffmin(t1, t_max); false as soon as t_max <= t_min.  Both roundings are monotone in `face`, so for two boxes
+// L inside B (min_B <= min_L, max_L <= max_B on every axis) and the SAME origin and direction bits, the computed slab of B
+// contains the computed slab of L on every axis: t0_B <= t0_L and t1_B >= t1_L, hence after every axis t_min_B <= t_min_L and
+// t_max_B >= t_max_L — if L is not rejected, B is not (all values finite: hot lane, bounded scene; BVHNode::hit hands the same
+// t_min = 0.001, t_max = FLT_MAX down the tree, bvh.h:160-190).  The boxes of a leaf's ancestors contain the leaf's box
+// EXACTLY: surrounding_box is min / max of the children's bounds (aabb.h:58-66) and TransformAABB with rotation 0, position 0
+// returns its argument (transform.h:22-31; crt_bvh.cpp transform_aabb; tests/test_bvh.py checks the nesting bit for bit), at
+// build time and after every refit.  And on the hot chain every node at depth >= 2 sees the same direction c3.  So for a
+// leaf at depth >= 2:   the leaf's box passes with c3   ==>   every ancestor at depth >= 2 passes,
+// and the chain test is the leaf's box (staged next to the entry) + the root with c1 + the root's child on the leaf's side
+// with c2 — three nodes of the whole tree, which the tile's cone proves for all its rays almost everywhere.  Rounds 1-3
+// loaded and tested every unproven level per winner (chain_ok), or proved the chain from a hit point strictly inside the
+// leaf's box — which fails wherever the surface faces the camera along an axis (thin boxes, the hit next to a face of EVERY
+// box around it): the tiles there were the last of the frame to end.
+
+// Bits 0..2: every ray of the tile passes the root's box / its left child's / its right child's (box_all_hit with the
+// tile's cone); 0 when the root is a leaf.
+__device__ __forceinline__ unsigned tile_top_proven(const BvhTiles& bt, V3 o, const TileCone& cone) {
+    const float4 r0 = bt.nodes[0], r1 = bt.nodes[1];
+    if (((__float_as_int(r1.w) >> 24) & 3) != 0) return 0u;
+    const float4 l0 = bt.nodes[2], l1 = bt.nodes[3];
+    const int right = __float_as_int(l1.z);
+    const float4 q0 = bt.nodes[2 * (size_t)right], q1 = bt.nodes[2 * (size_t)right + 1];
+    return (box_all_hit(r0, r1, o, cone) ? 1u : 0u) | (box_all_hit(l0, l1, o, cone) ? 2u : 0u) | (box_all_hit(q0, q1, o, cone) ? 4u : 0u);
+}
+
+// Staged per list entry: the box of its leaf and flag = (leaf under the root's RIGHT child) | (leaf at depth < 2) << 1.
+__device__ __forceinline__ void stage_leaf(const BvhTiles& bt, int slot, int& flag, float4& box0, float2& box1) {
+    const int info = bt.slot_leaf[slot];
+    const int depth = (info >> 24) & 31;
+    const int* __restrict__ path = bt.anc + (size_t)(info & 0xffffff) * bt.anc_stride;
+    const int leaf = path[depth];
+    flag = ((depth >= 1 && path[1] != 1) ? 1 : 0) | (depth < 2 ? 2 : 0);
+    const float4 l0 = bt.nodes[2 * (size_t)leaf], l1 = bt.nodes[2 * (size_t)leaf + 1];
+    box0 = l0;
+    box1 = make_float2(l1.x, l1.y);
+}
+
+// A box no ray from `o` passes, whatever its direction: min == max on an axis (an axis-aligned triangle; a ground plane) and o
+// off that plane — both quotients of the axis are the same finite or infinite value q, so t_min >= q >= t_max after it
+// (aabb.h:40).  With o ON the plane the quotients are 0 / d: zero, or NaN for d = 0, which ffmin / ffmax drop: not decided here.
+__device__ __forceinline__ bool box_never_hit(float4 box0, float2 box1, V3 o) {
+    return (box0.x == box0.w && o.x != box0.x) || (box0.y == box1.x && o.y != box0.y) || (box0.z == box1.y && o.z != box0.z);
+}
+
+// Hot lane, leaf at depth >= 2: its box with c3.
+__device__ __forceinline__ bool leaf_box_hit(float4 box0, float2 box1, V3 o, V3 c3) {
+    const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
+    return box_hit_fast(box0, make_float4(box1.x, box1.y, 0.0f, 0.0f), o, c3, y3);
+}
+// Does this entry need more than its leaf's box?  (top: tile_top_proven)
+__device__ __forceinline__ bool chain_needs_top(int flag, unsigned top) {
+    return (flag & 2) != 0 || (top & 1u) == 0u || (top & ((flag & 1) ? 4u : 2u)) == 0u;
+}
+// The rest of the chain of a hot lane whose leaf passed: the root with c1 = d1 and its child on the leaf's side with
+// c2 = F(d1) (rotate(., 0) is the identity on a hot lane's directions); a leaf at depth < 2: the literal chain.
+__device__ __forceinline__ bool chain_top_ok(const BvhTiles& bt, int slot, int flag, V3 o, V3 d1, V3 c3) {
+    const V3 c2 = unit_vector_fast_ng(d1);
+    if (flag & 2) return chain_ok(bt, slot, 0, nullptr, o, d1, c2, c3);
+    const float4 r0 = bt.nodes[0], r1 = bt.nodes[1];
+    const int child = (flag & 1) ? __float_as_int(bt.nodes[3].z) : 1;
+    const float4 m0 = bt.nodes[2 * (size_t)child], m1 = bt.nodes[2 * (size_t)child + 1];
+    const V3 y1 = V3{reciprocal<true>(d1.x), reciprocal<true>(d1.y), reciprocal<true>(d1.z)};
+    const V3 y2 = V3{reciprocal<true>(c2.x), reciprocal<true>(c2.y), reciprocal<true>(c2.z)};
+    return box_hit_fast(r0, r1, o, d1, y1) && box_hit_fast(m0, m1, o, c2, y2);
+}
+// The same for a winner that is not staged (the unstaged rest of a shared tile's slice): leaf and flag from the tables.
+__device__ __forceinline__ bool chain_ok_hot(const BvhTiles& bt, int slot, unsigned top, V3 o, V3 d1, V3 c3) {
+    int flag;
+    float4 b0;
+    float2 b1;
+    stage_leaf(bt, slot, flag, b0, b1);
+    if ((flag & 2) == 0 && !leaf_box_hit(b0, b1, o, c3)) return false;
+    return !chain_needs_top(flag, top) || chain_top_ok(bt, slot, flag, o, d1, c3);
+}
+
 // The render kernel with world = the BVH: lane = pixel, wavefront = 8x8 tile, block = 16x16.
 template <bool FAST>
 __global__ void __launch_bounds__(256)

@@ -179,7 +179,8 @@ constexpr int kStatsWaveSlots = 8192;                 // timeline: per wave (blo
 constexpr int kStatsWaveLog = kStatsWords;            // start, end of the heavy phase, end; then entries << 32 | tile of the block's last shared tile
 constexpr int kStatsSampleBlocks = 4, kStatsSampleSlots = 256;   // timeline: blocks 0..3 log (draws done, slices done) per sample
 constexpr int kStatsSampleLog = kStatsWaveLog + 4 * kStatsWaveSlots;
-constexpr int kStatsTotalWords = kStatsSampleLog + 2 * kStatsSampleBlocks * kStatsSampleSlots;
+constexpr int kStatsLightLog = kStatsSampleLog + 2 * kStatsSampleBlocks * kStatsSampleSlots;   // timeline: per wave, its last light tile with geometry:
+constexpr int kStatsTotalWords = kStatsLightLog + 3 * kStatsWaveSlots;                          // start stamp; tile | entries << 32 | such tiles taken << 48
 
 // BVH world (crt_bvh_kernels.hpp).  d_nodes: 2 float4 per node, preorder with skip links
 // (layout there); d_rec / d_shade_n are in leaf ("slot") order.  fast: bounded scene (host check).

@@ -1637,7 +1637,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     const bool timeline = stats_in != nullptr && stats_in[kStatsTimeline] != 0ull;
     unsigned long long* __restrict__ stats = timeline ? nullptr : stats_in;
     const unsigned long long wall0 = timeline ? (unsigned long long)wall_clock64() : 0ull;
-    unsigned long long tl_heavy = 0ull;
+    unsigned long long tl_heavy = 0ull, tl_light = 0ull, tl_light_t = 0ull, tl_counts = 0ull, tl_light_end = 0ull;
     __shared__ unsigned long long best_key[64];   // per pixel: min over the waves of (ordered t, index)
     __shared__ float ray_d[3][64];
     __shared__ unsigned s_item;
@@ -1654,14 +1654,11 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
     constexpr int kPairCap = (VREC && WAVES <= 8) ? 512 : 1;
     __shared__ unsigned short lpairs[(VREC && WAVES <= 8) ? WAVES : 1][kPairCap];   // (pixel | entry << 6 | cull-sure << 12)
     __shared__ unsigned long long lkey[(VREC && WAVES <= 8) ? WAVES : 1][64];       // per pixel: min (ordered t, index)
-    __shared__ __attribute__((aligned(16))) int lpath[BVH ? WAVES : 1][32];        // BVH mode: node indices of the tile's reference path
-    // BVH mode, staged tiles: per list entry its slot, (leaf depth | first level to test << 8 | 1 << 16 when more than
-    // kChainBatch levels remain), and the node indices of those levels — the chain test then needs ONE round of loads
+    // BVH mode, staged tiles: per list entry its slot, the box of its LEAF (min.xyz, max.x | max.yz) and a flag (stage_leaf): on
+    // the hot chain the winner's chain of boxes is its leaf's box + the root + one child of the root (crt_bvh_kernels.hpp,
+    // "the chain of boxes of a winner"), so the common sample needs no node loads at all
     __shared__ int lslot[BVH ? WAVES : 1][BVH ? kStage : 1];
-    __shared__ int linfo[BVH ? WAVES : 1][BVH ? kStage : 1];
-    __shared__ __attribute__((aligned(16))) int lnodes[BVH ? WAVES : 1][BVH ? kStage : 1][kChainBatch];
-    // ... and the box of its LEAF (min.xyz, max.x | max.yz): a ray whose hit point lies strictly inside it passes every box of the chain
-    // (hit_inside_leaf_box), so the common sample needs no node loads at all
+    __shared__ int lflag[BVH ? WAVES : 1][BVH ? kStage : 1];
     __shared__ float4 lbox0[BVH ? WAVES : 1][BVH ? kStage : 1];
     __shared__ float2 lbox1[BVH ? WAVES : 1][BVH ? kStage : 1];
 
@@ -1780,50 +1777,28 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 stage_candidates<kStage>(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, slice_mine, n_lds, lane, x,
                                          global_row(p.row_begin, p.strip_rows, p.strip_step, ly), cand);
             }
-            // BVH mode: the levels of the tree proven hit for every ray of the tile along its first entry's path (every wave
-            // works it out for itself, into its own lpath), and for a staged slice — like a light tile's list — per entry:
-            // the tree's tie order with the entry's place (wave, position) in the low bits of the key, its slot, where its
-            // path leaves the reference path, and the node indices of the levels from there on.  The master then finds the
-            // winner's staged data one LDS read away and needs ONE round of node loads for the chain test (rounds 1-2 went
-            // through slot_leaf, the ancestor table and the nodes: three dependent round trips per sample, 3.3 us of the
-            // 7.5 us a shared tile's sample took).
-            int first_level_h = 0;
+            // BVH mode: which of the root's and its children's boxes every ray of the tile passes (tile_top_proven), and for a staged
+            // slice — like a light tile's list — per entry: the tree's tie order with the entry's place (wave, position) in the
+            // low bits of the key, its slot, its leaf's box.  The master then finds the winner's staged data one LDS read away
+            // and tests its chain without node loads (rounds 1-2 went through slot_leaf, the ancestor table and the nodes: three
+            // dependent round trips per sample, 3.3 us of the 7.5 us a shared tile's sample took; round 3 one round of loads).
+            unsigned top_h = 0u;
             if (BVH && !tree_tile && !skip_item) {
                 const BvhTiles& bt = bvh;
                 const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-                const TileCone cone = tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, tly0));
-                first_level_h = __builtin_amdgcn_readfirstlane(
-                    tile_reference_path(bt, __builtin_amdgcn_readfirstlane((int)(lst[0] & 0x7fffffffu)), o, cone, lpath[wave], lane));
+                if (wave == 0) top_h = tile_top_proven(bt, o, tile_cone(p, hx0, global_row(p.row_begin, p.strip_rows, p.strip_step, tly0)));
                 if (n_lds > 0) {
+                    bool dead = false;
                     if (lane < n_lds) {
                         const int slot = slice_mine & 0x7fffffff;
                         // key: (tie order, 22 bits: smaller wins = later leaf, first in its leaf) | wave | position (host: at most 2^22 triangles)
                         lent[wave][lane] = (int)(((unsigned)slice_mine & kCullSureBit) | ((unsigned)(0x3fffff - bt.partner[slot]) << 9) |
                                                  ((unsigned)wave << 6) | (unsigned)lane);
-                        const int info = bt.slot_leaf[slot];
-                        const int depth = (info >> 24) & 31;
-                        const int* __restrict__ path = bt.anc + (size_t)(info & 0xffffff) * bt.anc_stride;
-                        int first_k = first_level_h;   // where this entry's path leaves the reference path, if earlier
-                        for (int k = 0; k < first_level_h && k <= depth; k += 4) {
-                            const int4 ids = *reinterpret_cast<const int4*>(path + k);
-                            const int4 ref = *reinterpret_cast<const int4*>(&lpath[wave][k]);
-                            int d = 4;
-                            if (ids.w != ref.w) d = 3;
-                            if (ids.z != ref.z) d = 2;
-                            if (ids.y != ref.y) d = 1;
-                            if (ids.x != ref.x) d = 0;
-                            if (d < 4) { first_k = min(first_k, k + d); break; }
-                        }
-                        first_k = min(first_k, depth);   // the leaf's own box is always tested
                         lslot[wave][lane] = slot;
-                        linfo[wave][lane] = depth | (first_k << 8) | ((depth - first_k + 1 > kChainBatch) ? (1 << 16) : 0);
-#pragma unroll
-                        for (int j = 0; j < kChainBatch; ++j) lnodes[wave][lane][j] = path[min(first_k + j, depth)];
-                        const int leaf = path[depth];
-                        const float4 l0 = bt.nodes[2 * (size_t)leaf], l1 = bt.nodes[2 * (size_t)leaf + 1];
-                        lbox0[wave][lane] = l0;
-                        lbox1[wave][lane] = make_float2(l1.x, l1.y);
+                        stage_leaf(bt, slot, lflag[wave][lane], lbox0[wave][lane], lbox1[wave][lane]);
+                        dead = box_never_hit(lbox0[wave][lane], lbox1[wave][lane], o);
                     }
+                    cand.lo &= ~(unsigned)__builtin_amdgcn_ballot_w64(dead);   // (see the light tiles)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1874,7 +1849,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 // pixel alone from the tile's whole list (general_winner + chain_ok_general, excluding what fails).
                 const BvhTiles& bt = bvh;
                 const V3 o = V3{p.cam.origin[0], p.cam.origin[1], p.cam.origin[2]};
-                const int first_level = first_level_h;   // the tile's reference path is in lpath[0] (this wave's)
+                const unsigned top = top_h;
                 int tl_sample_bvh = 0;   // timeline mode: (slices done, chains checked) per sample of the first blocks' first tile
                 render_pixel<true, false, false, !MAT, MAT>(p, x, ly, shade_n, state, rgb, lane_valid,
                              [&](V3 d1, V3, float& closest, int& hit_idx, auto&&... hit_branch_draws) {
@@ -1909,46 +1884,17 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                     if (hot && kbest != ~0ull) {
 #endif
                         const int qk = (int)(unsigned)(kbest & 0xffffffffull);
-                        if (qk & 32) {   // an unstaged entry of a long slice: the slot through the tie order, the chain through the tables
+                        if (qk & 32) {   // an unstaged entry of a long slice: the slot through the tie order, leaf and flag through the tables
                             slot = bt.partner[0x3fffff - ((qk >> 9) & 0x3fffff)];
-                            alone = !chain_ok(bt, slot, first_level, lpath[0], o, d1, unit_vector_fast_ng(d1), c3);   // hot lane: c1 = d1, c2 = F(d1)
+                            alone = !chain_ok_hot(bt, slot, top, o, d1, c3);
                         } else {         // staged: the winner's wave and position are in the key
                             const int sw = (qk >> 6) & 7, kw = qk & 31;
                             slot = lslot[sw][kw];
-                            const int info = linfo[sw][kw];
-                            const bool inside = hit_inside_leaf_box(lbox0[sw][kw], lbox1[sw][kw], o, c3, key_t(kbest));
-                            if (__builtin_amdgcn_ballot_w64(!inside) == 0ull) {
-                                alone = false;      // every winner of this sample is reached: no node loads
-                            } else if (inside) {
-                                alone = false;
-                            } else if (info >> 16) {   // more levels than one batch: the general routine (global loads)
-                                alone = !chain_ok(bt, slot, first_level, lpath[0], o, d1, unit_vector_fast_ng(d1), c3);
-                            } else {
-                                const V3 c1 = d1, c2 = unit_vector_fast_ng(d1);   // hot lane: rotate(., 0) is the identity on its directions
-                                const int depth = info & 31, first_k = (info >> 8) & 31;
-                                int node[kChainBatch];
-                                float4 na[kChainBatch], nb[kChainBatch];
-#pragma unroll
-                                for (int j = 0; j < kChainBatch; ++j) node[j] = lnodes[sw][kw][j];
-#pragma unroll
-                                for (int j = 0; j < kChainBatch; ++j) {
-                                    na[j] = bt.nodes[2 * (size_t)node[j]];
-                                    nb[j] = bt.nodes[2 * (size_t)node[j] + 1];
-                                }
-                                const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
-                                bool ok = true;
-#pragma unroll
-                                for (int j = 0; j < kChainBatch; ++j) {
-                                    const int lv = min(first_k + j, depth);
-                                    V3 d = c3, y = y3;
-                                    if (lv < 2) {
-                                        d = sel3(lv == 0, c1, c2);
-                                        y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
-                                    }
-                                    ok = ok && box_hit_fast(na[j], nb[j], o, d, y);
-                                }
-                                alone = !ok;
-                            }
+                            const int flag = lflag[sw][kw];
+                            bool ok = (flag & 2) != 0 || leaf_box_hit(lbox0[sw][kw], lbox1[sw][kw], o, c3);
+                            const bool rest = ok && chain_needs_top(flag, top);
+                            if (__builtin_amdgcn_ballot_w64(rest) != 0ull && rest) ok = chain_top_ok(bt, slot, flag, o, d1, c3);
+                            alone = !ok;
                         }
                     }
                     if (alone) {   // per lane, over the tile's whole list, with the literal chain
@@ -2075,6 +2021,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         // six waves per SIMD they were spilled to scratch (one v_mov per tile instead of a scratch reload per use)
         int lane = lane_k;
         asm volatile("" : "+v"(lane));
+        if (timeline && tl_light_t != 0ull && tl_light_end == 0ull) tl_light_end = (unsigned long long)wall_clock64();
         const unsigned c_len = ((n_groups + (unsigned)(kLightChunks - 1 - chunk)) / kLightChunks) * kLightGroup;   // positions of this chunk
         unsigned pos = 0xffffffffu;
         if (c_len != 0u) {
@@ -2109,6 +2056,12 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 #if CRT_PRIO
         if (cnt != 0) __builtin_amdgcn_s_setprio(CRT_PRIO_GEOM); else __builtin_amdgcn_s_setprio(CRT_PRIO_SKY);
 #endif
+        if (timeline && cnt != 0) {
+            tl_light_t = (unsigned long long)wall_clock64();
+            tl_light = ((tl_light + (1ull << 48)) & 0xffff000000000000ull) | ((unsigned long long)(unsigned)cnt << 32) | (unsigned)tile_id;
+            tl_counts = 0ull;
+            tl_light_end = 0ull;
+        }
         const uint32_t* __restrict__ lst = w.pool + __builtin_amdgcn_readfirstlane(desc.x);
         const int x0 = (tile_id % w.tiles_x) * 8, ly0 = (tile_id / w.tiles_x) * 8;
         const int x = x0 + (lane & 7), ly = ly0 + (lane >> 3);
@@ -2141,40 +2094,22 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             }
             stage_candidates<kStage>(lrec[wave], lqw[wave], lent[wave], p, cls, n_pad, rec, mine0, cnt, lane, px,
                                      global_row(p.row_begin, p.strip_rows, p.strip_step, ply), cand);
-            // levels of the tree proven hit for every ray of this tile (along the first entry's path)
-            const TileCone cone = tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0));
-            const int first_level = __builtin_amdgcn_readfirstlane(
-                tile_reference_path(bt, __builtin_amdgcn_readfirstlane(mine0 & 0x7fffffff), o, cone, lpath[wave], lane));
+            // the root's and its children's boxes: proven for every ray of this tile?
+            const unsigned top = __builtin_amdgcn_readfirstlane(
+                tile_top_proven(bt, o, tile_cone(p, x0, global_row(p.row_begin, p.strip_rows, p.strip_step, ly0))));
+            bool dead = false;
             if (lane < cnt) {
                 // The tree's tie order instead of the slot — smaller wins (larger partner = later leaf, first in its leaf) —
                 // with the entry's position in the low 6 bits, so the winner's staged data is one LDS read away.
                 const int slot = mine0 & 0x7fffffff;
                 lent[wave][lane] = (int)(((unsigned)mine0 & kCullSureBit) | ((unsigned)(0xffffff - bt.partner[slot]) << 6) | (unsigned)lane);
-                const int info = bt.slot_leaf[slot];
-                const int depth = (info >> 24) & 31;
-                const int* __restrict__ path = bt.anc + (size_t)(info & 0xffffff) * bt.anc_stride;
-                int first_k = first_level;   // where this entry's path leaves the reference path, if earlier
-                for (int k = 0; k < first_level && k <= depth; k += 4) {
-                    const int4 ids = *reinterpret_cast<const int4*>(path + k);
-                    const int4 ref = *reinterpret_cast<const int4*>(&lpath[wave][k]);
-                    int d = 4;
-                    if (ids.w != ref.w) d = 3;
-                    if (ids.z != ref.z) d = 2;
-                    if (ids.y != ref.y) d = 1;
-                    if (ids.x != ref.x) d = 0;
-                    if (d < 4) { first_k = min(first_k, k + d); break; }
-                }
-                first_k = min(first_k, depth);   // the leaf's own box is always tested
-                const int n_lv = depth - first_k + 1;
                 lslot[wave][lane] = slot;
-                linfo[wave][lane] = depth | (first_k << 8) | ((n_lv > kChainBatch) ? (1 << 16) : 0);
-#pragma unroll
-                for (int j = 0; j < kChainBatch; ++j) lnodes[wave][lane][j] = path[min(first_k + j, depth)];
-                const int leaf = path[depth];
-                const float4 l0 = bt.nodes[2 * (size_t)leaf], l1 = bt.nodes[2 * (size_t)leaf + 1];
-                lbox0[wave][lane] = l0;
-                lbox1[wave][lane] = make_float2(l1.x, l1.y);
+                stage_leaf(bt, slot, lflag[wave][lane], lbox0[wave][lane], lbox1[wave][lane]);
+                dead = box_never_hit(lbox0[wave][lane], lbox1[wave][lane], o);
             }
+            // entries whose leaf's box no ray from this origin passes (a flat box: an axis-aligned triangle, a ground plane) are no
+            // candidates of any pixel: found as winners they were excluded and the walk repeated, sample after sample
+            cand.lo &= ~(unsigned)__builtin_amdgcn_ballot_w64(dead);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2211,7 +2146,6 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                 unsigned excl = 0u;
                 for (bool first = true;; first = false) {
                     int q = -1;
-                    float t_win = 0.0f;   // the winner's t (the reference's rec.t): the hit point o + t * c3 decides whether the chain needs loads
                     if (first && bp != 0xffffffffu) {
                         lkey[wave][lane] = ~0ull;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2226,57 +2160,30 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         const unsigned long long kb = lkey[wave][lane];
                         q = (kb == ~0ull) ? -1 : (int)(unsigned)(kb & 0xffffffffull);
-                        t_win = key_t(kb);
                     } else {
                         Cand rest = cand;
                         rest.lo &= ~excl;
                         float tb = FLT_MAX;
                         trace_candidates<kStage>(lrec[wave], lent[wave], rest, c3, tb, q);
-                        t_win = tb;
                     }
                     int slot = -1;
                     bool bad = false;
                     const int kw = q & 31;   // the winner's position in the staged list (kStage = 32)
-                    // the winner's hit point strictly inside its leaf's box: every box of its chain is passed, no loads
-                    const bool chain_sure = q >= 0 && hot && hit_inside_leaf_box(lbox0[wave][kw], lbox1[wave][kw], o, c3, t_win);
-                    const bool need_chain = q >= 0 && hot && !chain_sure;
-                    if (q >= 0 && hot) slot = lslot[wave][kw];
-#ifdef CRT_DBG_NOCHAIN   // timing experiment only: the chain of boxes is not tested (wrong pixels where it matters)
-                    if (false) {
-#else
-                    if (__builtin_amdgcn_ballot_w64(need_chain) != 0ull && need_chain) {
+                    if (q >= 0 && hot) {
+                        // the winner's chain of boxes: its leaf's box with c3 (staged), and — where the tile's cone does not prove them,
+                        // or the leaf sits right under the root — the root and its child on the leaf's side (node loads: rare)
+                        slot = lslot[wave][kw];
+#ifndef CRT_DBG_NOCHAIN   // (defined: timing experiment only — the chain of boxes is not tested, wrong pixels where it matters)
+                        const int flag = lflag[wave][kw];
+                        bool ok = (flag & 2) != 0 || leaf_box_hit(lbox0[wave][kw], lbox1[wave][kw], o, c3);
+                        const bool rest = ok && chain_needs_top(flag, top);
+                        if (__builtin_amdgcn_ballot_w64(rest) != 0ull && rest) ok = chain_top_ok(bt, slot, flag, o, d1, c3);
+                        bad = !ok;
 #endif
-                        // (hot lane: rotate(., 0) is the identity on its directions, so c1 = d1 and c2 = one normalisation on)
-                        const V3 c1 = d1, c2 = unit_vector_fast_ng(d1);
-                        const int info = linfo[wave][kw];
-                        if (info >> 16) {   // more levels than one batch: the general routine (global loads)
-                            bad = !chain_ok(bt, slot, first_level, lpath[wave], o, c1, c2, c3);
-                        } else {
-                            const int depth = info & 31, first_k = (info >> 8) & 31;
-                            int node[kChainBatch];
-                            float4 na[kChainBatch], nb[kChainBatch];
-#pragma unroll
-                            for (int j = 0; j < kChainBatch; ++j) node[j] = lnodes[wave][kw][j];
-#pragma unroll
-                            for (int j = 0; j < kChainBatch; ++j) {
-                                na[j] = bt.nodes[2 * (size_t)node[j]];
-                                nb[j] = bt.nodes[2 * (size_t)node[j] + 1];
-                            }
-                            const V3 y3 = V3{reciprocal<true>(c3.x), reciprocal<true>(c3.y), reciprocal<true>(c3.z)};
-                            bool ok = true;
-#pragma unroll
-                            for (int j = 0; j < kChainBatch; ++j) {
-                                const int lv = min(first_k + j, depth);
-                                V3 d = c3, y = y3;
-                                if (lv < 2) {
-                                    d = sel3(lv == 0, c1, c2);
-                                    y = V3{reciprocal<true>(d.x), reciprocal<true>(d.y), reciprocal<true>(d.z)};
-                                }
-                                ok = ok && box_hit_fast(na[j], nb[j], o, d, y);
-                            }
-                            bad = !ok;
-                        }
                     }
+#ifdef CRT_TL_COUNTS   // diagnostic build: wave-samples of the wave's last geometry tile with an unreachable winner
+                    if (timeline) tl_counts += __builtin_amdgcn_ballot_w64(bad) != 0ull ? 1ull : 0ull;
+#endif
                     if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
                         if (hot) hit_idx = slot;
                         closest = 0.0f;   // not used after the traversal
@@ -2377,6 +2284,10 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             stats_in[kStatsWaveLog + 4 * gw + 2] = wall2;
             // the block's last shared tile: entries << 44 | tile << 20, and the wave's place (HW_REG_HW_ID: wave, SIMD, CU, SE)
             stats_in[kStatsWaveLog + 4 * gw + 3] = (tl_heavy << 20) | (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xfffffu);
+            stats_in[kStatsLightLog + 2 * gw + 0] = tl_light_t;
+            stats_in[kStatsLightLog + 2 * gw + 1] = tl_light;
+            // ... its duration in ticks (low 20 bits); CRT_TL_COUNTS builds: four 11-bit counts above
+            stats_in[kStatsLightLog + 2 * kStatsWaveSlots + gw] = ((tl_light_end - tl_light_t) & 0xfffffull) | (tl_counts << 20);
         }
     }
 }

@@ -53,7 +53,8 @@ int crt_set_kernel_variant(int variant);
  * crt_debug_wave_timeline (4 words per wavefront, index = block * waves per block + wave; returns
  * the number of wavefront slots copied, at most max_waves).  max_waves == -1 reads the per-sample
  * log of blocks 0..3 instead (their first shared tile, list world): 4 x 256 pairs of time stamps
- * (master's draws done, slices done); `out` then holds 2048 words. */
+ * (master's draws done, slices done); `out` then holds 2048 words.  max_waves == -2: per wavefront its last
+ * light tile with geometry — start stamp; tile | entries << 32 | such tiles taken << 48 — 2 x 8192 words. */
 int crt_debug_tiled_stats(int enable, uint64_t *out48);
 int crt_debug_wave_timeline(uint64_t *out, int max_waves);
 

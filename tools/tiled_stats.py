@@ -73,7 +73,26 @@ for rep in range(6):
             continue
         print("   block %d per-sample us: median %.2f max %.2f (sample %d), samples over 3x the median: %d; master's wait for the slices after its draws: median %.2f max %.2f"
               % (b, np.median(per), per.max(), int(per.argmax()) + 1, int((per > 3 * np.median(per)).sum()), np.median(wait), wait.max()))
+ll = api.light_timeline()[: len(api.wave_timeline())].astype(np.int64)
+ll = ll[api.wave_timeline()[:, 2] > 0]
+late = np.argsort(-end)[:12]
+dur = (ll[:, 2] & 0xfffff) / 100.0
+cnts = ll[:, 2] >> 20
+print("last frame, the waves that end last: " + "; ".join(
+    "end %.0f: last geometry tile (%d, %d) %d entries started %.0f took %.0f us, %d such tiles, heavy phase until %.0f [wave-samples with chain loads %d, lanes %d, of which x face %d, other %d]" %
+    (end[i], (ll[i, 1] & 0xffffffff) % tx, (ll[i, 1] & 0xffffffff) // tx, (ll[i, 1] >> 32) & 0xffff, (ll[i, 0] - t0) / 100.0, dur[i], ll[i, 1] >> 48, mid[i],
+     cnts[i] & 0x7ff, (cnts[i] >> 11) & 0x7ff, (cnts[i] >> 22) & 0x7ff, (cnts[i] >> 33) & 0x7ff) for i in late))
+has = (ll[:, 1] >> 48) > 0
+print("duration of the waves' last geometry tile, us: p10 %.0f median %.0f p90 %.0f p99 %.0f max %.0f; by entries:" % tuple(np.percentile(dur[has], [10, 50, 90, 99, 100])),
+      "; ".join("%d-%d: median %.0f max %.0f (%d)" % (a, b, np.median(dur[has & (e >= a) & (e <= b)]), dur[has & (e >= a) & (e <= b)].max(), (has & (e >= a) & (e <= b)).sum())
+                for e in [(ll[:, 1] >> 32) & 0xffff] for a, b in [(1, 4), (5, 8), (9, 16), (17, 32), (33, 64)] if (has & (e >= a) & (e <= b)).any()))
+slow = np.argsort(-np.where(has, dur, 0))[:10]
+print("slowest: " + "; ".join("(%d, %d) %d entries %.0f us" % ((ll[i, 1] & 0xffffffff) % tx, (ll[i, 1] & 0xffffffff) // tx, (ll[i, 1] >> 32) & 0xffff, dur[i]) for i in slow))
+ng = ll[:, 1] >> 48
+print("geometry tiles per wave: histogram", np.bincount(ng)[:12].tolist(), "; duration of a wave's last geometry tile until its end (upper bound) us: median %.0f p90 %.0f max %.0f"
+      % tuple(np.percentile((end - (ll[:, 0] - t0) / 100.0)[ng > 0], [50, 90, 100])))
 edges = np.arange(0, end.max() + 25.0, 25.0)
 print("last frame, wave ends per 25 us:", np.histogram(end, edges)[0].tolist())
 print("last frame, heavy phase ends per 25 us (waves):", np.histogram(mid, edges)[0].tolist())
 L.crt_debug_tiled_stats(0, None)
+print("raw light log rows:", ll[:4].tolist())
