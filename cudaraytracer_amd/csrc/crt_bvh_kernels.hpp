@@ -717,24 +717,6 @@ __device__ __forceinline__ int general_winner_all(const BvhTiles& bt, const floa
     return best_q;
 }
 
-// Per tile, wave-uniform: the reference path = the path of `slot0` (copied to tile_path, LDS), and the first of its
-// levels whose box is not proven hit for every ray of the tile.
-__device__ __forceinline__ int tile_reference_path(const BvhTiles& bt, int slot0, V3 o, const TileCone& cone, int* __restrict__ tile_path, int lane) {
-    const int info = bt.slot_leaf[slot0];
-    const int ord = info & 0xffffff, depth = (info >> 24) & 31;
-    const int* __restrict__ path = bt.anc + (size_t)ord * bt.anc_stride;
-    if (lane < 32) tile_path[lane] = (lane <= depth) ? path[lane] : -1;
-    int first = depth + 1;
-    for (int k = 0; k <= depth; ++k) {   // uniform addresses: scalar loads
-        const int node = path[k];
-        if (!box_all_hit(bt.nodes[2 * (size_t)node], bt.nodes[2 * (size_t)node + 1], o, cone)) { first = k; break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return first;
-}
-
 // ---- the chain of boxes of a winner on the hot chain, without walking it (round 4) ------------------------------------
 // AABB::hit (aabb.h:30-42) per axis: q(face) = fl(fl(face - o) / d), t0 = ffmin(q(min), q(max)), t1 = ffmax(..); t_min = ffmax(t0,
 // t_min); t_max = ffmin(t1, t_max); false as soon as t_max <= t_min.  Both roundings are monotone in `face`, so for two boxes

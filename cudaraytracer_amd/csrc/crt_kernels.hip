@@ -1448,22 +1448,6 @@ __device__ __forceinline__ float key_t(unsigned long long key) {
     return __uint_as_float((ordered & 0x80000000u) ? (ordered & 0x7fffffffu) : ~ordered);
 }
 
-// BVH mode: is the chain of boxes of a winner passed for sure?  The boxes of a leaf's ancestors contain the leaf's box
-// (surrounding_box, aabb.h:58-66), so a ray that passes through a point STRICTLY inside the leaf's box — by a margin
-// that covers (i) the rounding of every quotient of AABB::hit (2^-22 relative to the slab distances), (ii) the few ulp
-// by which the directions of the levels (c1, c2, c3) differ, t * 2^-22 at the hit point, (iii) the rounding of the
-// point itself — has t_min < t < t_max on every axis of every one of those boxes, with t > 0.001: AABB::hit returns true
-// at every level.  The point is the hit point o + t * c3 of the triangle that won.  A flat box (a zero extent: never
-// hit, aabb.h:40) has no interior, a hit too close to a face or to the eye is not proven: those take the node loads.
-__device__ __forceinline__ bool hit_inside_leaf_box(float4 b0, float2 b1, V3 o, V3 c3, float t) {
-    const float px = o.x + t * c3.x, py = o.y + t * c3.y, pz = o.z + t * c3.z;
-    const float at = fabsf(t) * 1.0e-6f;
-    const float mx = 1.0e-4f * (b0.w - b0.x) + 2.0e-6f * (fabsf(o.x) + fabsf(px)) + at;
-    const float my = 1.0e-4f * (b1.x - b0.y) + 2.0e-6f * (fabsf(o.y) + fabsf(py)) + at;
-    const float mz = 1.0e-4f * (b1.y - b0.z) + 2.0e-6f * (fabsf(o.z) + fabsf(pz)) + at;
-    return t >= 0.01f && t <= 1.0e30f && px - b0.x > mx && b0.w - px > mx && py - b0.y > my && b1.x - py > my && pz - b0.z > mz && b1.y - pz > mz;
-}
-
 // ---- balanced candidate walk.  The step count of trace_candidates is the LONGEST per-pixel list
 // of the wavefront while the mean is much shorter.  When the (pixel, entry) pairs of the staged
 // entries fit the wave's pair buffer they are laid out once per tile, evenly over the lanes:
@@ -1522,6 +1506,18 @@ __device__ __forceinline__ void trace_pairs(Area& area, const int* ent, const un
     }
 }
 
+// A wave-uniform 32-bit value in an SGPR of its own (see shade_tiles_kernel).
+__device__ __forceinline__ float sgpr_copy(float x) {
+    float y;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(y) : "s"(x));
+    return y;
+}
+__device__ __forceinline__ int sgpr_copy(int x) {
+    int y;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(y) : "s"(x));
+    return y;
+}
+
 // ---- far pairs: the balanced walk for a slice of a shared tile that is LONGER than its staging area.  Rounds 1-3 staged the
 // first 64 entries and walked the rest with wave-uniform records — every lane tests every remaining entry whatever its pixel,
 // one scalar-memory round trip per entry: 46 entries cost a 768-entry tile 10 us per sample, 219 entries cost the ~1 980-entry
@@ -1533,6 +1529,12 @@ __device__ __forceinline__ void trace_pairs(Area& area, const int* ent, const un
 // the pool word two steps ahead, the record one step ahead of the test.
 // Returns the number of pairs, or 0xffffffff when they do not fit `cap` words (the caller then stages as before).
 constexpr int kFarMaxSlice = 1024;
+#ifndef CRT_NO_FAR          // A/B switches of tuning builds
+#define CRT_NO_FAR 0
+#endif
+#ifndef CRT_NO_TL_LIGHT
+#define CRT_NO_TL_LIGHT 0
+#endif
 __device__ __forceinline__ unsigned build_far_pairs(unsigned short* __restrict__ out, unsigned cap, const RenderParams& p,
                                                     const float4* __restrict__ cls, int n_pad, const uint32_t* __restrict__ lst,
                                                     int first, int step, int n, int lane, bool valid, int x, int y_global,
@@ -1614,22 +1616,36 @@ __device__ __forceinline__ void trace_far_pairs(const unsigned short* far, unsig
 // yields slot lists.  A triangle is hit through the tree iff it passes Triangle::collision_detection
 // (with the direction of its depth: c3 on the hot chain) AND the boxes of its leaf and of all the
 // leaf's ancestors pass AABB::hit; the tile's list is a superset of the first condition, so per
-// sample the staged walk finds every pixel's winner under the tree's tie order (BvhTiles::partner),
-// chain_ok checks that winner's boxes — once per hit pixel, at full lane utilisation — and a
-// winner whose chain fails is excluded for that pixel and the walk repeated (rare).  Tiles with more
-// than 32 survivors (or without a list) and wave-samples off the hot direction chain take the
-// tree itself (bvh_trace).  Heavy tiles keep the 8-wave scheme: the master wave publishes c3, merges the slices' keys and
-// checks the winner's chain.
+// sample the staged walk finds every pixel's winner under the tree's tie order (BvhTiles::partner) and the
+// winner's chain is checked — once per hit pixel, at full lane utilisation: on the hot chain that is the
+// leaf's box (staged in LDS), which implies every ancestor from depth 2 on, plus the root and one of its
+// children where the tile's cone does not prove them (crt_bvh_kernels.hpp, "the chain of boxes of a winner");
+// a winner whose chain fails is excluded for that pixel and the walk repeated (rare); entries whose leaf's
+// box no ray can pass are dropped when the tile is staged.  Tiles with more than 32 survivors are shared by
+// the block (the master wave publishes c3, merges the slices' keys and checks the winner's chain); tiles
+// without a list and wave-samples off the hot direction chain take the tree itself (bvh_trace) or the
+// literal chain (general_winner, chain_ok_general).
 // FULL: the launch policy of a full frame as compile-time constants — light tiles dealt in groups of four, no row slabs except
 // four for the list world's heaviest class — instead of the decode of split_packed that small launches (one rank's strips),
 // test hooks and the tuning build need (round 3 decoded it in every launch: +2 % on the bench frame's shading kernel, same-box
 // A/B in profiles/r4/ab_r2_vs_head.txt).
 template <bool VREC, int OCC, int WAVES, bool BVH = false, bool MAT = false, bool FULL = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC)
-shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
+shade_tiles_kernel(RenderParams p_arg, const float* __restrict__ rec, const float4* __restrict__ cls, int n_pad,
                    const float* __restrict__ shade_n, uint32_t* __restrict__ state, float* __restrict__ rgb,
                    TiledWork w, unsigned long long* __restrict__ stats_in, int dbg_repeat_in, BvhTiles bvh,
                    unsigned split_packed, MatView mv) {
+    // The scalars of `p` that the per-sample code reads, as registers of their own: the kernel's arguments arrive in 16-dword
+    // tuples (s_load_dwordx16), a tuple is spilled and reloaded as a whole, and with a few more values live across the
+    // shared-tile phase (the far pairs) hipcc spilled the tuple that holds the albedo — 20 v_readlane per hit sample of
+    // every light tile, +3.5 % on the bench frame.
+    // (a real s_mov each: an empty asm with a tied operand is coalesced back into the tuple's sub-register)
+    RenderParams p = p_arg;
+    p.albedo[0] = sgpr_copy(p_arg.albedo[0]);
+    p.albedo[1] = sgpr_copy(p_arg.albedo[1]);
+    p.albedo[2] = sgpr_copy(p_arg.albedo[2]);
+    p.samples = sgpr_copy(p_arg.samples);
+    p.nx = sgpr_copy(p_arg.nx);
     // bvh by value: its pointers come with the kernel's arguments and are global memory to the compiler (loaded from a struct in
     // device memory they were generic: 119 FLAT loads in the BVH mode — which cost nothing measurable, 1.16 against 1.17 ms)
     // diagnostics: stats_in[kStatsTimeline] != 0 selects the light-weight timeline (wave start/end times only), which
@@ -1758,7 +1774,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             const bool tree_tile = BVH && (walk_all || !VREC);
             // list world, a slice longer than the staging area: all of it as far pairs (build_far_pairs), nothing staged
             unsigned n_far = 0xffffffffu, n_far_all = 0u;
-            if (!BVH && VREC && WAVES <= 8 && !walk_all && cnt_w > kStage && cnt_w <= kFarMaxSlice && dbg_pairs != 0)
+            if (!CRT_NO_FAR && !BVH && VREC && WAVES <= 8 && __builtin_expect(!walk_all && cnt_w > kStage && cnt_w <= kFarMaxSlice && dbg_pairs != 0, 0))
                 n_far = build_far_pairs(reinterpret_cast<unsigned short*>(&lrec[wave]), (unsigned)(sizeof(Area) / sizeof(unsigned short)), p, cls, n_pad,
                                         lst, swave, slice_waves, cnt_w, lane, lane_valid, x,
                                         global_row(p.row_begin, p.strip_rows, p.strip_step, ly), stats != nullptr, n_far_all);
@@ -1811,7 +1827,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
             }
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
-                if (!BVH && far) {
+                if (!CRT_NO_FAR && !BVH && __builtin_expect(far, 0)) {
                     if (n_far != 0u)
                         trace_far_pairs(reinterpret_cast<const unsigned short*>(&lrec[wave]), n_far, rec, lst, swave, slice_waves, lane,
                                         [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key);
@@ -2021,7 +2037,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
         // six waves per SIMD they were spilled to scratch (one v_mov per tile instead of a scratch reload per use)
         int lane = lane_k;
         asm volatile("" : "+v"(lane));
-        if (timeline && tl_light_t != 0ull && tl_light_end == 0ull) tl_light_end = (unsigned long long)wall_clock64();
+        if (!CRT_NO_TL_LIGHT && timeline && tl_light_t != 0ull && tl_light_end == 0ull) tl_light_end = (unsigned long long)wall_clock64();
         const unsigned c_len = ((n_groups + (unsigned)(kLightChunks - 1 - chunk)) / kLightChunks) * kLightGroup;   // positions of this chunk
         unsigned pos = 0xffffffffu;
         if (c_len != 0u) {
@@ -2056,7 +2072,7 @@ shade_tiles_kernel(RenderParams p, const float* __restrict__ rec, const float4* 
 #if CRT_PRIO
         if (cnt != 0) __builtin_amdgcn_s_setprio(CRT_PRIO_GEOM); else __builtin_amdgcn_s_setprio(CRT_PRIO_SKY);
 #endif
-        if (timeline && cnt != 0) {
+        if (!CRT_NO_TL_LIGHT && timeline && cnt != 0) {
             tl_light_t = (unsigned long long)wall_clock64();
             tl_light = ((tl_light + (1ull << 48)) & 0xffff000000000000ull) | ((unsigned long long)(unsigned)cnt << 32) | (unsigned)tile_id;
             tl_counts = 0ull;

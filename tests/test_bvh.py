@@ -234,6 +234,21 @@ def assert_same_tree(scene, bvh):
     assert np.array_equal(slots, bvh.order())
 
 
+def assert_nested(scene):
+    """Every inner node's box contains its children's boxes EXACTLY (compared as floats, bounds equal or outside): what lets the
+    tiled kernels' BVH mode test a winner's leaf box instead of its chain (crt_bvh_kernels.hpp, "the chain of boxes of a winner")."""
+    boxes, meta, _ = scene.bvh_export()
+    inner = np.where(meta[:, 2] == 0)[0]
+    assert len(inner) > 0
+    left = inner + 1
+    right = meta[left, 0]
+    for child in (left, right):
+        assert (boxes[inner, :3] <= boxes[child, :3]).all() and (boxes[inner, 3:] >= boxes[child, 3:]).all()
+    # ... and tightly: every bound of a parent is the bound of one of its children
+    assert np.array_equal(boxes[inner, :3], np.minimum(boxes[left, :3], boxes[right, :3]))
+    assert np.array_equal(boxes[inner, 3:], np.maximum(boxes[left, 3:], boxes[right, 3:]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 9])
 @pytest.mark.parametrize("name", sorted(BVH_GOLDEN))
@@ -246,6 +261,8 @@ def test_gpu_bvh_matches_golden(gpu, golden_dir, name, variant):
     scene, cam = make(BVH_GOLDEN[name](), nx, ny)
     (rgb,), states = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
     boxes, meta, slots = scene.bvh_export()
+    if variant == 0 and len(boxes) > 1:
+        assert_nested(scene)
     assert np.array_equal(bits(boxes), bits(g["boxes"]))
     assert np.array_equal(meta[:, 0], g["skip"]) and np.array_equal(meta[:, 3], g["depth"])
     assert np.array_equal(slots, g["order"])
@@ -312,6 +329,7 @@ def test_gpu_bvh_refit_and_frame_loop(gpu, oracle):
         refs.append(r)
     outs, _ = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, frames=3, poses=poses)
     assert_same_tree(scene, bvh)                                  # after two refits
+    assert_nested(scene)
     for f in range(3):
         skip = 0 if f == 0 else 1                                 # pixel 0 of later frames: state[0] race
         assert np.array_equal(bits(outs[f]).reshape(-1, 3)[skip:], bits(refs[f]).reshape(-1, 3)[skip:]), f
@@ -386,6 +404,7 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
         tri = c[:, None, :] + rng.uniform(-1.2, 1.2, (n, 3, 3))
         tri[::2, :, 2] = tri[::2, :1, 2]                      # every other triangle lies in a plane z = const
         tri[1::4, :, 0] = tri[1::4, :1, 0]                    # some in x = const
+        tri[5::16, :, 0] = 0.0                                # ... and some in the plane x = 0 THROUGH the eye (0 / d quotients: not dropped at staging)
     elif kind == "dense":
         n = 600
         c = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(-9, -5, n)], axis=-1)
