@@ -1034,11 +1034,12 @@ int render_impl(const crt_scene* scene, const crt_camera* camera, crt_rng* rng, 
         // Primary rays ride the tiled kernels (binning over the slot-ordered triangles, the tree only for every
         // pixel's winner: shade_tiles_kernel<.., BVH>) whenever the list world's tiled variant is eligible and
         // the fast arithmetic holds; variant 1 (and the test hooks 5, 6) select the per-ray tree walk.
-        if (fast && tiled_ok && scene->n_tris <= (1 << 22) && (g_variant == 0 || g_variant == 2 || g_variant == 7)) {   // (22 bits of tie order in the keys)
+        // (variant 10: test hook — shared tiles from 4 entries on, dealt out as row slabs, like the list world's)
+        if (fast && tiled_ok && scene->n_tris <= (1 << 22) && (g_variant == 0 || g_variant == 2 || g_variant == 7 || g_variant == 10)) {   // (22 bits of tie order in the keys)
             int rc = ensure_workspace(cx, nx, row_count, scene->n_tris);
             if (rc != CRT_OK) return rc;
             HIP_TRY(crt::launch_frame_prepass(scene->bvh->d_base_slots, scene->n_tris, scene->n_pad, p, cx.d_rec, cx.d_cls, cx.w, stream));
-            HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, 1, &cx.w,
+            HIP_TRY(crt::launch_render(p, cx.d_rec, cx.d_cls, scene->n_pad, scene->bvh->d_shade_n_slots, rng->d_state, d_rgb, g_variant == 10 ? 5 : 1, &cx.w,
                                        cx.n_cus, true, g_d_stats, timing ? cx.ev_mid : nullptr, &cx.cache_bvh, true, stream,
                                        &scene->bvh->tiles_view, g_variant == 7, materials));
             cx.ev_has_mid = true;

@@ -1574,18 +1574,25 @@ __device__ __forceinline__ RecV load_rec_lane(const float* __restrict__ rec, uns
 }
 
 // One sample over the far pairs (n >= 1) of the slice lst[first + pos * step]: minima into keys[pixel].
-template <class RayOf>
+// KEYED (BVH mode: the list holds slots): what orders ties and comes back in the key is the tree's order,
+// (0x3fffff - partner[slot]) << 9 | tag (walk_list_strided_keyed's keys: the master looks the slot up through the partner table).
+template <bool KEYED, class RayOf>
 __device__ __forceinline__ void trace_far_pairs(const unsigned short* far, unsigned n, const float* __restrict__ rec,
                                                 const uint32_t* __restrict__ lst, int first, int step, int lane, RayOf ray_of,
-                                                unsigned long long* keys) {
+                                                unsigned long long* keys, const int* __restrict__ partner = nullptr, unsigned tag = 0u) {
     const unsigned ln = (unsigned)lane;
     unsigned w0 = far[ln < n ? ln : 0u], w1 = far[ln + 64u < n ? ln + 64u : 0u];
     unsigned e0 = lst[first + (int)(w0 >> 6) * step], e1 = lst[first + (int)(w1 >> 6) * step];
     RecV cur = load_rec_lane(rec, e0 & 0x7fffffffu);
+    int k0 = KEYED ? partner[e0 & 0x7fffffffu] : 0;
     for (unsigned base = 0; base < n; base += 64u) {
         RecV nxt = cur;
+        int k1 = k0;
         unsigned w2 = w1, e2 = e1;
-        if (base + 64u < n) nxt = load_rec_lane(rec, e1 & 0x7fffffffu);   // in flight while this step's record is tested
+        if (base + 64u < n) {   // in flight while this step's record is tested
+            nxt = load_rec_lane(rec, e1 & 0x7fffffffu);
+            if (KEYED) k1 = partner[e1 & 0x7fffffffu];
+        }
         if (base + 128u < n) {
             w2 = far[base + 128u + ln < n ? base + 128u + ln : 0u];
             e2 = lst[first + (int)(w2 >> 6) * step];
@@ -1594,9 +1601,10 @@ __device__ __forceinline__ void trace_far_pairs(const unsigned short* far, unsig
         const V3 dp = ray_of(pix);
         float t_pair = FLT_MAX;
         int i_pair = -1;
-        exact_test_lane<true>(cur, (int)(e0 & 0x7fffffffu), (e0 & kCullSureBit) != 0u, base + ln < n, dp, t_pair, i_pair);
+        const int idx = KEYED ? (int)(((unsigned)(0x3fffff - k0) << 9) | tag) : (int)(e0 & 0x7fffffffu);
+        exact_test_lane<true>(cur, idx, (e0 & kCullSureBit) != 0u, base + ln < n, dp, t_pair, i_pair);
         if (i_pair >= 0) atomicMin(&keys[pix], hit_key(t_pair, i_pair));
-        w0 = w1; e0 = e1; cur = nxt;
+        w0 = w1; e0 = e1; cur = nxt; k0 = k1;
         w1 = w2; e1 = e2;
     }
 }
@@ -1626,7 +1634,7 @@ __device__ __forceinline__ void trace_far_pairs(const unsigned short* far, unsig
 // without a list and wave-samples off the hot direction chain take the tree itself (bvh_trace) or the
 // literal chain (general_winner, chain_ok_general).
 // FULL: the launch policy of a full frame as compile-time constants — light tiles dealt in groups of four, no row slabs except
-// four for the list world's heaviest class — instead of the decode of split_packed that small launches (one rank's strips),
+// for the heaviest class (four; eight in the BVH mode) — instead of the decode of split_packed that small launches (one rank's strips),
 // test hooks and the tuning build need (round 3 decoded it in every launch: +2 % on the bench frame's shading kernel, same-box
 // A/B in profiles/r4/ab_r2_vs_head.txt).
 template <bool VREC, int OCC, int WAVES, bool BVH = false, bool MAT = false, bool FULL = false>
@@ -1695,7 +1703,7 @@ shade_tiles_kernel(RenderParams p_arg, const float* __restrict__ rec, const floa
     // that take the slabs run side by side — the longest chain of a launch gets shorter by the split factor, down to
     // the master wave's own per-sample work.
     auto split_of = [&](int c) -> unsigned {   // log2 of the row slabs a heavy tile of class c is dealt out as
-        if (FULL) return (!BVH && c == 0) ? 2u : 0u;
+        if (FULL) return c == 0 ? (BVH ? 3u : 2u) : 0u;
         return (split_packed >> (3 * c)) & 7u;
     };
     unsigned total_heavy = 0;
@@ -1774,12 +1782,12 @@ shade_tiles_kernel(RenderParams p_arg, const float* __restrict__ rec, const floa
             const bool tree_tile = BVH && (walk_all || !VREC);
             // list world, a slice longer than the staging area: all of it as far pairs (build_far_pairs), nothing staged
             unsigned n_far = 0xffffffffu, n_far_all = 0u;
-            if (!CRT_NO_FAR && !BVH && VREC && WAVES <= 8 && __builtin_expect(!walk_all && cnt_w > kStage && cnt_w <= kFarMaxSlice && dbg_pairs != 0, 0))
+            if (!CRT_NO_FAR && VREC && WAVES <= 8 && __builtin_expect(!walk_all && cnt_w > kStage && cnt_w <= kFarMaxSlice && dbg_pairs != 0, 0))
                 n_far = build_far_pairs(reinterpret_cast<unsigned short*>(&lrec[wave]), (unsigned)(sizeof(Area) / sizeof(unsigned short)), p, cls, n_pad,
                                         lst, swave, slice_waves, cnt_w, lane, lane_valid, x,
                                         global_row(p.row_begin, p.strip_rows, p.strip_step, ly), stats != nullptr, n_far_all);
             const bool far = n_far != 0xffffffffu;
-            if (stats && lane == 0 && !BVH && VREC && !walk_all && cnt_w > kStage) {   // slices as far pairs, their pairs, slices that did not fit, the most pairs of a slice
+            if (stats && lane == 0 && VREC && !walk_all && cnt_w > kStage) {   // slices as far pairs, their pairs, slices that did not fit, the most pairs of a slice
                 atomicAdd(&stats[43], far ? 1ull : 0ull);
                 atomicAdd(&stats[44], far ? (unsigned long long)n_far : 0ull);
                 atomicAdd(&stats[45], far ? 0ull : 1ull);
@@ -1827,10 +1835,11 @@ shade_tiles_kernel(RenderParams p_arg, const float* __restrict__ rec, const floa
             }
             auto trace_slice = [&](V3 d2, float& closest, int& hit_idx) {
               for (int rep = 0; rep < dbg_repeat; ++rep) {
-                if (!CRT_NO_FAR && !BVH && __builtin_expect(far, 0)) {
+                if (!CRT_NO_FAR && __builtin_expect(far, 0)) {
                     if (n_far != 0u)
-                        trace_far_pairs(reinterpret_cast<const unsigned short*>(&lrec[wave]), n_far, rec, lst, swave, slice_waves, lane,
-                                        [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key);
+                        trace_far_pairs<BVH>(reinterpret_cast<const unsigned short*>(&lrec[wave]), n_far, rec, lst, swave, slice_waves, lane,
+                                             [&](int pix) { return V3{ray_d[0][pix], ray_d[1][pix], ray_d[2][pix]}; }, best_key,
+                                             BVH ? bvh.partner : nullptr, ((unsigned)wave << 6) | 32u);
                     continue;
                 }
                 if (slice_pairs != 0xffffffffu)
@@ -2519,10 +2528,11 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     // small launch is the 64-sample chain of EVERY tile that holds geometry (about 2 us per sample whatever the list's
     // length), not the longest list; splitting the common classes only replicates the master wave's work (+20 .. +90 %).
     // So the default is no split — except for lists of more than 768 entries (the two ~1 980-entry pole tiles of the C5 frame end
-    // its launch alone: 4.83 -> 4.06 ms with four slabs each, profiles/r3_tiled/c5_split.txt); list world only (the BVH mode's
-    // shared tiles are tested without slabs).  The mechanism stays for the tuning build (CRT_SPLIT).
+    // its launch alone: 4.83 -> 4.06 ms with four slabs each, profiles/r3_tiled/c5_split.txt; round 4: with their slices as far pairs 0.3 ms).
+    // The mechanism stays for the tuning build (CRT_SPLIT) and the test hook (variant 5).
     int split[kHeavyClasses] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (d_bvh_tiles == nullptr) split[0] = 2;
+    // (BVH mode: eight slabs of one row — its staging areas hold 32 entries, so the far pairs of a slice of a quarter tile would not fit)
+    split[0] = d_bvh_tiles == nullptr ? 2 : 3;
     // ... and for launches with few tiles per CU (one rank's strips of an 8-way split), together with two slabs per light tile
     // that holds geometry (light_split below): slowest rank 0.309 -> 0.280 ms on C3, 0.407 -> 0.374 ms on C3B
     // (profiles/r3_tiled/sweep_light_split_*.txt) — the machine is idle enough there for the replicated ray set-up not to matter
@@ -2572,7 +2582,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     (void)occ;
 #endif
     // the full-frame policy as compile-time constants (shade_tiles_kernel<.., FULL>) when this launch's policy is exactly that
-    unsigned full_packed = (4u << 27) | (d_bvh_tiles == nullptr ? 2u : 0u);
+    unsigned full_packed = (4u << 27) | (d_bvh_tiles == nullptr ? 2u : 3u);
     const bool full = split_packed == full_packed && group == 8;
     if (full && d_bvh_tiles == nullptr && materials == nullptr && vrec) fn = shade_tiles_kernel<true, 6, 8, false, false, true>;
     if (d_bvh_tiles) {   // the tree as the world (shade_tiles_kernel<.., BVH = true>)

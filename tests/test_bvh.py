@@ -250,7 +250,7 @@ def assert_nested(scene):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 9])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7, 9, 10])
 @pytest.mark.parametrize("name", sorted(BVH_GOLDEN))
 def test_gpu_bvh_matches_golden(gpu, golden_dir, name, variant):
     """Tree (boxes, structure, leaf order) and frame equal the oracle's: primary rays through the
@@ -436,7 +436,7 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
     bvh = oracle.Bvh(w, states)
     ref, states = oracle.render_bvh(bvh, ocam, nx, ny, spp, states)
     after = np.concatenate([states["d"][:, None], states["v"]], axis=1)
-    for variant in (0, 1, 7, 9):
+    for variant in (0, 1, 7, 9, 10):                            # 10: shared tiles from 4 entries on, dealt out as row slabs
         if kind == "stack" and variant == 0:
             api.tiled_stats(1)
         (rgb,), st = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=variant)
@@ -444,6 +444,27 @@ def test_gpu_bvh_tiled_equals_tree_walk_on_adversarial_scenes(gpu, oracle, kind,
             assert api.tiled_stats(0)[6] == n                  # the scene does what it was built for: a tile with all 2050 entries
         assert np.array_equal(bits(rgb), bits(ref)), (kind, variant, int((bits(rgb) != bits(ref)).any(axis=2).sum()))
         assert np.array_equal(st[1:], after[1:]), (kind, variant)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lat,n_lon,nx,ny", [(8, 3000, 320, 180), (6, 12000, 256, 144)])
+def test_gpu_bvh_pole_tiles_longer_than_the_staging_areas(gpu, n_lat, n_lon, nx, ny):
+    """The BVH world over a lat-long sphere with many meridians: the pole tiles' slices are longer than the 32-entry staging
+    areas and go as far pairs with the tree's tie order in the keys (trace_far_pairs<KEYED>), the heaviest as eight row slabs;
+    the second mesh overflows the pair areas (staged + keyed wave-uniform walk).  Tiled == per-ray tree walk, pixels and states,
+    also with every shared tile dealt out as row slabs (variant 10)."""
+    sc = scenes.displaced_sphere(n_lat, n_lon, amp=0.02)
+    scene, cam = make(sc, nx, ny)
+    spp = 5
+    api.tiled_stats(1)
+    (tiled,), st_t = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=0)
+    stats = api.tiled_stats(0)
+    assert stats[43] > 0 and stats[44] > 0, stats[43:47]
+    (walk,), st_w = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=1, build=False)
+    (slabs,), st_s = hip_bvh_frames(gpu, scene, cam, nx, ny, spp, variant=10, build=False)
+    flat = lambda a: bits(a).reshape(-1, 3)[1:]                # pixel 0 reads stream 0, which the build (first call only) advanced
+    assert np.array_equal(flat(tiled), flat(walk)) and np.array_equal(flat(slabs), flat(walk))
+    assert np.array_equal(st_t[1:], st_w[1:]) and np.array_equal(st_s[1:], st_w[1:])
 
 
 @pytest.mark.gpu
