@@ -208,8 +208,10 @@ int ensure_workspace(Context& ws, int nx, int rows, int n_tris) {
         HIP_TRY(hipMalloc(&ws.w.counters, crt::kCtrWords * sizeof(uint32_t)));
         ws.w.counters64 = reinterpret_cast<unsigned long long*>(ws.w.counters);
     }
+    // (the log is cut into kLogSegments segments, a wavefront appends to the one its block index selects: the bound for a tiny
+    // scene — every wavefront, every tile — holds per segment)
     const size_t want_log = std::min<size_t>(std::min<size_t>(std::max<size_t>(std::max<size_t>(tiles * 16, waves * 32), (size_t)1 << 16),
-                                                              waves * tiles + 256), (size_t)1 << 27);
+                                                              (waves * tiles + 256) * crt::kLogSegments), (size_t)1 << 27);
     if (want_log > ws.log_entries) {
         if (ws.w.log) (void)hipFree(ws.w.log);
         ws.w.log = nullptr;

@@ -116,13 +116,18 @@ constexpr int kCtrQueueLen = 2;      // counters[0..1] alias counters64[0]; [2 +
 // Consumer cursors of the shading kernel.  Returning atomics on one address serialise in L2
 // (~60 ns each, measured), so every hot cursor has its own 128-byte line and the light queue
 // is cut into kLightChunks chunks with one cursor each.
-constexpr int kCtrLogCursor = 24;                  // records appended to TiledWork::log
+constexpr int kLogSegments = 32;                   // TiledWork::log is cut into this many segments of log_cap / kLogSegments records, each with
+                                                   // its own cursor on its own 128-byte line (kCtrLogCursor + s * kCtrLine): a binning wavefront
+                                                   // appends to segment (its block index) % kLogSegments.  One cursor for all (rounds 1-3) was one
+                                                   // L2 line taking a returning atomic from every wavefront, 20 ns each, one after the other:
+                                                   // 15 625 wavefronts = 0.32 ms of the C5 frame, 33 us of the bench frame.
 constexpr int kCtrLogOverflow = 25;                // != 0: the log was full, every tile walks the whole list
 constexpr int kCtrLine = 32;                       // words per 128-byte line
 constexpr int kCtrHeavyCursor = 2 * kCtrLine;      // next item of the concatenated heavy classes
 constexpr int kLightChunks = 64;
 constexpr int kCtrLightCursor = 3 * kCtrLine;      // + k * kCtrLine: next position inside chunk k
-constexpr int kCtrWords = (3 + kLightChunks) * kCtrLine;
+constexpr int kCtrLogCursor = (3 + kLightChunks) * kCtrLine;   // + s * kCtrLine: records appended to segment s of TiledWork::log
+constexpr int kCtrWords = (3 + kLightChunks + kLogSegments) * kCtrLine;
 
 // Occupancy of the persistent shading kernel, queried once per launch context and kernel.
 struct LaunchCache {

@@ -915,6 +915,8 @@ constexpr int kRegionTilesX = kRegionW / 8, kRegionTilesY = kRegionH / 8;
 constexpr int kBinThreads = 64;
 constexpr int kBinWavesMin = 16384;   // the screen is cut into slices of region rows (blockIdx.y) / columns (blockIdx.z)
                                      // until the launch has this many wavefronts: few large triangles are not one wave's work
+constexpr int kBigRegions = 16;     // a triangle whose box spans at least this many regions is worked on its own (bin_big)
+constexpr int kDirectTiles = 12;    // a triangle whose box touches at most this many tiles (and rows, and columns) tests them itself (bin_direct)
 constexpr int kFewTriangles = 8;     // a region with at most this many candidates is classified lane = tile (measured: 4..16 equal, 0 and 32+ slower)
 
 struct FormSet {          // the five affine forms of one triangle (dn, a, su, dq, w = a - su - dq)
@@ -958,24 +960,46 @@ __device__ __forceinline__ void bin_log_flush(BinRecord* slog, unsigned& n_log, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned seg = (blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u) % (unsigned)kLogSegments, seg_cap = w.log_cap / (unsigned)kLogSegments;
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&w.counters[kCtrLogCursor], n_log);
+    if (lane == 0) base = atomicAdd(&w.counters[kCtrLogCursor + seg * kCtrLine], n_log);
     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if ((unsigned long long)base + n_log > (unsigned long long)w.log_cap) {
+    if ((unsigned long long)base + n_log > (unsigned long long)seg_cap) {
         if (lane == 0) w.counters[kCtrLogOverflow] = 1u;   // bin_alloc_kernel then gives every tile the whole list
     } else {
-        for (unsigned k = (unsigned)lane; k < n_log; k += 64u) w.log[base + k] = slog[k];
+        for (unsigned k = (unsigned)lane; k < n_log; k += 64u) w.log[(size_t)seg * seg_cap + base + k] = slog[k];
     }
     n_log = 0u;
     __builtin_amdgcn_wave_barrier();
 }
 
+// The local rows [ly_a, ly_b] of this launch whose GLOBAL rows lie in [g_a, g_b] (none: ly_b < ly_a).  The launch's rows are
+// strips of strip_rows rows every strip_rows * strip_step (global_row), so the map is monotone over the rows it owns.
+__device__ __forceinline__ void local_rows(const RenderParams& p, int g_a, int g_b, int& ly_a, int& ly_b) {
+    const int period = p.strip_rows * p.strip_step;
+    const int da = max(g_a - p.row_begin, 0), db = g_b - p.row_begin;
+    int sa = da / period, ra = da - sa * period;
+    if (ra >= p.strip_rows) { sa += 1; ra = 0; }
+    ly_a = sa * p.strip_rows + ra;
+    ly_b = -1;
+    if (db >= 0) {
+        const int sb = db / period, rb = min(db - sb * period, p.strip_rows - 1);
+        ly_b = min(sb * p.strip_rows + rb, p.row_count - 1);
+    }
+}
+
 __global__ void __launch_bounds__(kBinThreads)
 bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledWork w,
-               unsigned long long* __restrict__ stats, int few_triangles) {
+               unsigned long long* __restrict__ stats_in, int few_triangles) {
     __shared__ BinRecord slog[kBinLogCap];
     unsigned n_log = 0u;   // wave-uniform
     unsigned n_region_hit = 0, n_tile_box = 0, n_tile_hit = 0;   // diagnostics (wave-uniform)
+    // diagnostics: the timeline mode (crt_debug_tiled_stats(2)) keeps this kernel's timing intact and records, on the 100 MHz
+    // device clock, the last end of a wavefront (slot 30) and the longest wavefront: ticks << 40 | ticks after slot 29's
+    // reference (the first wavefront that got there) << 24 | block (slot 31)
+    const bool timeline = stats_in != nullptr && stats_in[kStatsTimeline] != 0ull;
+    unsigned long long* __restrict__ stats = timeline ? nullptr : stats_in;
+    const unsigned long long wall0 = timeline ? (unsigned long long)wall_clock64() : 0ull;
     const long long clk0 = stats ? (long long)clock64() : 0;
     const int tri = blockIdx.x * kBinThreads + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1006,13 +1030,66 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
                               !(bb.z > v_last + hv_t) && !(bb.y < u_first - hu_t) && !(bb.x > u_last + hu_t);
         if (__builtin_amdgcn_ballot_w64(in_slice) == 0ull) return;
     }
-    // Region range of the wavefront's union box (a superset is enough: every region is still
+    // Small triangles (round 4): a lane whose box touches at most kDirectTiles tiles of this launch tests THOSE tiles itself,
+    // one per step (bin_direct below) — the walk over the union of the wavefront's boxes tested 174 tiles per wavefront on the
+    // C3 frame (191 on C5) for the 15 that hold a survivor.  The tile range comes from the same thresholds the walk compares the
+    // tile centres with (tu_lo .. tv_hi), one tile of margin each way; every tile in it then passes through the walk's own
+    // float tests, so both routes select the same (tile, triangle) pairs.
+    const float tu_lo = bb.x - hu_t, tu_hi = bb.y + hu_t, tv_lo = bb.z - hv_t, tv_hi = bb.w + hv_t;
+    int dtx0 = 0, dnx = 0, dty0 = 0, dny = 0;
+    bool small = false;
+    if (have && fabsf(bb.x) < 1.0e3f && fabsf(bb.y) < 1.0e3f && fabsf(bb.z) < 1.0e3f && fabsf(bb.w) < 1.0e3f &&   // (NaN fails; the conversions
+        p.nx < (1 << 20) && p.ny < (1 << 20)) {                                                                      //  below stay in int range)
+        // columns: centre (tx * 8 + 4) / nx within [tu_lo, tu_hi]; 0.01 tile covers the rounding of the float comparison (1e-4)
+        const int tx_a = max((int)ceilf((tu_lo * (float)p.nx - 4.0f) * 0.125f - 0.01f), rx_begin * kRegionTilesX);
+        const int tx_b = min((int)floorf((tu_hi * (float)p.nx - 4.0f) * 0.125f + 0.01f), min(rx_end * kRegionTilesX, w.tiles_x) - 1);
+        // rows: tiles whose first GLOBAL pixel row g has g + 4 within [tv_lo, tv_hi] * ny; the rows of this launch are strips of
+        // strip_rows rows every strip_rows * strip_step (global_row): ly_a = the first local row at or above g_a, ly_b = the last
+        // at or below g_b; tiles start at local rows that are multiples of 8
+        const int g_a = (int)ceilf(tv_lo * (float)p.ny - 4.08f), g_b = (int)floorf(tv_hi * (float)p.ny - 3.92f);
+        int ly_a, ly_b;
+        local_rows(p, g_a, g_b, ly_a, ly_b);
+        const int ty_a = max((ly_a + 7) >> 3, ry_begin * kRegionTilesY);
+        const int ty_b = min(ly_b >> 3, min(ry_end * kRegionTilesY, w.tiles_y) - 1);
+        dtx0 = tx_a; dty0 = ty_a;
+        dnx = max(tx_b - tx_a + 1, 0); dny = (ly_b < 0) ? 0 : max(ty_b - ty_a + 1, 0);
+        small = dnx * dny <= kDirectTiles && dnx <= kDirectTiles && dny <= kDirectTiles;
+    }
+    // Big lanes (round 4): a triangle whose box spans many regions — an edge-on sliver on the silhouette: its relaxed hit set is a
+    // long thin strip across the screen — made the walk below scan the whole rectangle of regions around it, one region per
+    // step with 63 lanes idle: ONE such wavefront lasted as long as the whole kernel (340 of 400 us on the C5 frame, 45 of 46 us
+    // on the bench frame; tools/bin_timeline.py).  Such a lane is now taken out of the walk and worked on its own (bin_big
+    // below): 64 regions of ITS rectangle per step, lane = region, then the 64 tiles of every region that passes, lane = tile —
+    // the float tests of the walk's two levels with the same operands, so the same (tile, triangle) pairs.
+    int brx0 = 0, bnx = 0, bry0 = 0, bny = 0;
+    bool big = false;
+    if (have && !small && fabsf(bb.x) < 1.0e3f && fabsf(bb.y) < 1.0e3f && fabsf(bb.z) < 1.0e3f && fabsf(bb.w) < 1.0e3f &&
+        p.nx < (1 << 20) && p.ny < (1 << 20)) {
+        // regions whose centre ((rx * 128 + 64) / nx, (global row of the region's first row + 16) / ny) lies within the
+        // box + region slack: the walk's first test (s1_box), as integer ranges with the float test's rounding covered
+        const float ru_lo_ = bb.x - hu_r, ru_hi_ = bb.y + hu_r, rv_lo_ = bb.z - hv_r, rv_hi_ = bb.w + hv_r;
+        const int rx_a = max((int)ceilf((ru_lo_ * (float)p.nx - 64.0f) * (1.0f / kRegionW) - 0.01f), rx_begin);
+        const int rx_b = min((int)floorf((ru_hi_ * (float)p.nx - 64.0f) * (1.0f / kRegionW) + 0.01f), rx_end - 1);
+        int ly_a, ly_b;
+        local_rows(p, (int)ceilf(rv_lo_ * (float)p.ny - 16.3f), (int)floorf(rv_hi_ * (float)p.ny - 15.7f), ly_a, ly_b);
+        const int ry_a = max((ly_a + kRegionH - 1) / kRegionH, ry_begin), ry_b = min(ly_b / kRegionH, ry_end - 1);
+        brx0 = rx_a; bry0 = ry_a;
+        bnx = max(rx_b - rx_a + 1, 0); bny = (ly_b < 0) ? 0 : max(ry_b - ry_a + 1, 0);
+        big = bnx * bny >= kBigRegions;
+    }
+    const bool have_w = have && !small && !big;   // lanes that take the walk
+    // Region range of the walking lanes' union box (a superset is enough: every region is still
     // tested per lane): with a coherent triangle order it is a handful of the screen's regions.
     int rx_lo = rx_begin, rx_hi = rx_end, ry_lo = ry_begin, ry_hi = ry_end;
-    {
-        const bool odd = have && !(bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w);   // NaN box: keep everything
+#ifdef CRT_DBG_BIN_NOWALK   // timing experiment only (lists incomplete)
+    const bool any_walk = false;
+#else
+    const bool any_walk = __builtin_amdgcn_ballot_w64(have_w) != 0ull;
+#endif
+    if (any_walk) {
+        const bool odd = have_w && !(bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w);   // NaN box: keep everything
         if (__builtin_amdgcn_ballot_w64(odd) == 0ull) {
-            float u0 = have ? bb.x : 1.0e30f, u1 = have ? bb.y : -1.0e30f, v0 = have ? bb.z : 1.0e30f, v1 = have ? bb.w : -1.0e30f;
+            float u0 = have_w ? bb.x : 1.0e30f, u1 = have_w ? bb.y : -1.0e30f, v0 = have_w ? bb.z : 1.0e30f, v1 = have_w ? bb.w : -1.0e30f;
 #pragma unroll
             for (int ofs = 32; ofs > 0; ofs >>= 1) {
                 u0 = fminf(u0, __shfl_xor(u0, ofs, 64)); u1 = fmaxf(u1, __shfl_xor(u1, ofs, 64));
@@ -1032,7 +1109,6 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
         }
     }
     const float ru_lo = bb.x - hu_r, ru_hi = bb.y + hu_r;
-    const float tu_lo = bb.x - hu_t, tu_hi = bb.y + hu_t, tv_lo = bb.z - hv_t, tv_hi = bb.w + hv_t;
     const FormSet f = load_forms(cls, n_pad, have ? tri : 0);   // coalesced: 1 KiB per plane and wavefront
     float qt[5], qr[5];   // radius * 1.0001 + K * M on a tile / on a region
 #pragma unroll
@@ -1049,11 +1125,110 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float c[5];
-    for (int ry = ry_lo; ry < ry_hi; ++ry) {
+    {   // bin_direct: step k tests tile k of every small lane's own range; lanes that found the same tile share one record
+#ifdef CRT_DBG_BIN_NODIRECT   // timing experiment only (lists incomplete)
+        const int n_mine = 0;
+#else
+        const int n_mine = small ? dnx * dny : 0;
+#endif
+        int n_steps = n_mine;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) n_steps = max(n_steps, __shfl_xor(n_steps, ofs, 64));
+        int ix = 0, ty = dty0;
+        float vct = (float)(global_row(p.row_begin, p.strip_rows, p.strip_step, dty0 * 8) + 4) * rny;
+        for (int k = 0; k < n_steps; ++k) {
+            if (ix == dnx && k < n_mine) {   // next tile row of this lane's range
+                ix = 0;
+                ++ty;
+                vct = (float)(global_row(p.row_begin, p.strip_rows, p.strip_step, ty * 8) + 4) * rny;
+            }
+            const int tx = dtx0 + ix;
+            ++ix;
+            const int tile = ty * w.tiles_x + tx;
+            const float uct = (float)(tx * 8 + 4) * rnx;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) c[j] = __builtin_fmaf(uct, f.B[j], __builtin_fmaf(vct, f.C[j], f.A[j]));
+            const bool s2 = k < n_mine && !(vct < tv_lo) && !(vct > tv_hi) && !(uct < tu_lo) && !(uct > tu_hi) && cell_may_hit(c, qt);
+            const bool sure = s2 && c[0] > qt[0];
+            n_tile_box += 1u;
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(s2);
+            while (todo != 0ull) {
+                const int t_first = __builtin_amdgcn_readlane(tile, (int)__builtin_ctzll(todo));
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(s2 && tile == t_first);
+                const unsigned long long msure = __builtin_amdgcn_ballot_w64(sure && tile == t_first);
+                ++n_tile_hit;
+                if (n_log + 1u > (unsigned)kBinLogCap) bin_log_flush(slog, n_log, w, lane);
+                if (lane == 0) {
+                    atomicAdd(&w.tile_count[t_first], (unsigned)__builtin_popcountll(m));
+                    BinRecord r;
+                    r.tile = (uint32_t)t_first;
+                    r.base = (uint32_t)(blockIdx.x * kBinThreads);
+                    r.mask = m;
+                    r.sure = msure;
+                    slog[n_log] = r;
+                }
+                n_log += 1u;
+                todo &= ~m;
+            }
+        }
+    }
+    {   // bin_big: one big lane at a time, its values broadcast (wave-uniform: scalar operands — this is not the hot path)
+        auto bc = [&](float x, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src)); };
+        for (unsigned long long mbig = __builtin_amdgcn_ballot_w64(big); mbig != 0ull; mbig &= mbig - 1ull) {
+            const int src = (int)__builtin_ctzll(mbig);
+            const int rx0 = __builtin_amdgcn_readlane(brx0, src), nxr = __builtin_amdgcn_readlane(bnx, src);
+            const int ry0 = __builtin_amdgcn_readlane(bry0, src), n_reg = nxr * __builtin_amdgcn_readlane(bny, src);
+            float fA[5], fB[5], fC[5], sqt[5], sqr[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { fA[k] = bc(f.A[k], src); fB[k] = bc(f.B[k], src); fC[k] = bc(f.C[k], src); sqt[k] = bc(qt[k], src); sqr[k] = bc(qr[k], src); }
+            const float s_ru_lo = bc(ru_lo, src), s_ru_hi = bc(ru_hi, src), s_rv_lo = bc(rv_lo, src), s_rv_hi = bc(rv_hi, src);
+            const float s_tu_lo = bc(tu_lo, src), s_tu_hi = bc(tu_hi, src), s_tv_lo = bc(tv_lo, src), s_tv_hi = bc(tv_hi, src);
+            for (int base = 0; base < n_reg; base += 64) {   // lane = region of the rectangle
+                const int l = base + lane;
+                const int jy = l / nxr;
+                const int rx = rx0 + (l - jy * nxr), ry = ry0 + jy;
+                const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ry * kRegionH);
+                const float vcr = (float)(gy + kRegionH / 2) * rny, ucr = (float)(rx * kRegionW + kRegionW / 2) * rnx;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) c[k] = __builtin_fmaf(ucr, fB[k], __builtin_fmaf(vcr, fC[k], fA[k]));
+                const bool s1 = l < n_reg && !(vcr < s_rv_lo) && !(vcr > s_rv_hi) && !(ucr < s_ru_lo) && !(ucr > s_ru_hi) && cell_may_hit(c, sqr);
+                for (unsigned long long m1 = __builtin_amdgcn_ballot_w64(s1); m1 != 0ull; m1 &= m1 - 1ull) {   // lane = tile of a passing region
+                    const int lr = (int)__builtin_ctzll(m1);
+                    const int prx = __builtin_amdgcn_readlane(rx, lr), pry = __builtin_amdgcn_readlane(ry, lr), pgy = __builtin_amdgcn_readlane(gy, lr);
+                    ++n_region_hit;
+                    const int tx = prx * kRegionTilesX + (lane & (kRegionTilesX - 1)), lty = lane / kRegionTilesX;
+                    const int ty = pry * kRegionTilesY + lty;
+                    const bool tile_ok = tx < w.tiles_x && ty < w.tiles_y;
+                    const int tile = ty * w.tiles_x + tx;
+                    const float uct = (float)(tx * 8 + 4) * rnx, vct = (float)(pgy + lty * 8 + 4) * rny;
+                    float ct[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) ct[k] = __builtin_fmaf(uct, fB[k], __builtin_fmaf(vct, fC[k], fA[k]));
+                    const bool s2 = tile_ok && !(vct < s_tv_lo) && !(vct > s_tv_hi) && !(uct < s_tu_lo) && !(uct > s_tu_hi) && cell_may_hit(ct, sqt);
+                    n_tile_box += 64u;
+                    const unsigned long long ms = __builtin_amdgcn_ballot_w64(s2);
+                    if (ms == 0ull) continue;
+                    const unsigned n_rec = (unsigned)__builtin_popcountll(ms);
+                    if (n_log + n_rec > (unsigned)kBinLogCap) bin_log_flush(slog, n_log, w, lane);
+                    if (s2) {   // one record per surviving tile: this triangle alone
+                        atomicAdd(&w.tile_count[tile], 1u);
+                        BinRecord r;
+                        r.tile = (uint32_t)tile;
+                        r.base = (uint32_t)(blockIdx.x * kBinThreads);
+                        r.mask = 1ull << src;
+                        r.sure = (ct[0] > sqt[0]) ? (1ull << src) : 0ull;
+                        slog[n_log + (unsigned)__builtin_popcountll(ms & lanemask_lt)] = r;
+                    }
+                    n_log += n_rec;
+                }
+            }
+        }
+    }
+    for (int ry = ry_lo; any_walk && ry < ry_hi; ++ry) {
         // 32 local rows: inside one strip, so the region's global rows are contiguous
         const int gy = global_row(p.row_begin, p.strip_rows, p.strip_step, ry * kRegionH);
         const float vcr = (float)(gy + kRegionH / 2) * rny;
-        const bool in_row = have && !(vcr < rv_lo) && !(vcr > rv_hi);
+        const bool in_row = have_w && !(vcr < rv_lo) && !(vcr > rv_hi);
         if (__builtin_amdgcn_ballot_w64(in_row) == 0ull) continue;
         float row1[5];
 #pragma unroll
@@ -1147,6 +1322,13 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
     }
     __builtin_amdgcn_wave_barrier();
     bin_log_flush(slog, n_log, w, lane);
+    if (timeline && threadIdx.x == 0) {
+        const unsigned long long wall1 = (unsigned long long)wall_clock64();
+        unsigned long long ref = atomicCAS(&stats_in[29], 0ull, wall0);   // the first to arrive sets the reference
+        if (ref == 0ull) ref = wall0;
+        atomicMax(&stats_in[30], wall1 - ref + (1ull << 32));             // (+ 2^32: a wavefront that started before the reference stays positive)
+        atomicMax(&stats_in[31], ((wall1 - wall0) << 40) | (((wall0 - ref + (1ull << 15)) & 0xffffull) << 24) | (unsigned long long)(blockIdx.x & 0xffffffu));
+    }
     if (stats && lane == 0) {   // cells a wavefront walks, per level
         atomicAdd(&stats[0], 1ull);
         atomicAdd(&stats[1], (unsigned long long)n_region_hit);
@@ -1154,7 +1336,7 @@ bin_tri_kernel(RenderParams p, const float4* __restrict__ cls, int n_pad, TiledW
         atomicAdd(&stats[3], (unsigned long long)n_tile_hit);
         atomicMax(&stats[29], (unsigned long long)n_region_hit);     // the busiest wavefront
         atomicMax(&stats[30], (unsigned long long)n_tile_box);
-        atomicMax(&stats[31], (unsigned long long)(clock64() - clk0));
+        atomicMax(&stats[31], ((unsigned long long)(clock64() - clk0) << 24) | (unsigned long long)(blockIdx.x & 0xffffffu));   // cycles << 24 | wavefront
     }
 }
 
@@ -1240,10 +1422,13 @@ bin_alloc_kernel(TiledWork w, int heavy_min, unsigned shade_blocks, unsigned lon
 // (it is back at 0 afterwards); lists are unordered, the exact test breaks ties by index.
 __global__ void __launch_bounds__(256)
 bin_fill_kernel(TiledWork w) {
-    const unsigned n_rec = min(w.counters[kCtrLogCursor], w.log_cap);
     if (w.counters[kCtrLogOverflow] != 0u) return;   // every tile walks the whole list (bin_alloc_kernel)
-    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {
-        const BinRecord rec = w.log[r];
+    // block b works on segment b % kLogSegments of the log, together with the other gridDim.x / kLogSegments blocks of that segment
+    const unsigned seg_cap = w.log_cap / (unsigned)kLogSegments, seg = blockIdx.x % (unsigned)kLogSegments;
+    const unsigned n_rec = min(w.counters[kCtrLogCursor + seg * kCtrLine], seg_cap);
+    const unsigned per_seg = gridDim.x / (unsigned)kLogSegments;   // (the launch uses a multiple of kLogSegments blocks)
+    for (unsigned r = (blockIdx.x / (unsigned)kLogSegments) * blockDim.x + threadIdx.x; r < n_rec; r += per_seg * blockDim.x) {
+        const BinRecord rec = w.log[(size_t)seg * seg_cap + r];
         const uint2 desc = w.tile_desc[rec.tile];
         if (desc.y == kNoList) continue;
         const unsigned n = (unsigned)__builtin_popcountll(rec.mask);
@@ -2501,7 +2686,7 @@ hipError_t launch_render(const RenderParams& p, const float* d_rec, const float4
     }
     TiledWork w = *work;
     if (variant == 2) w.pool_cap = 4096;                 // test hook: force pool-full fallbacks
-    if (variant == 4) w.log_cap = 16;                    // test hook: the binning log overflows, every tile walks the whole list
+    if (variant == 4) w.log_cap = 16 * kLogSegments;   // (16 records per segment)                  // test hook: the binning log overflows, every tile walks the whole list
     // Blocks of 8 waves share a heavy tile (16-wave blocks have no LDS left for the balanced walk and
     // are slower at every launch size since it exists; kept for A/B through CRT_SHADE_GROUP).
     const int tiles_per_cu = w.tiles_total / std::max(n_cus, 1);

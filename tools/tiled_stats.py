@@ -34,7 +34,7 @@ print("bin wavefronts %d: regions entered %d (%.1f per wave), tiles box-tested %
 print("tiles %d  sum2 %d (avg %.1f) max2 %d overflow2 %d" % (o[4], o[5], o[5] / max(o[4], 1), o[6], o[7]))
 print("hist (bucket b: 2^(b-1) <= n < 2^b):", o[8:24])
 print("shade kernel cycles: heavy phase sum over blocks %d max %d | light phase sum over waves %d max %d | max wave total %d" % tuple(o[24:29]))
-print("bin busiest wavefront: regions %d, tiles box-tested %d, cycles %d" % tuple(o[29:32]))
+print("bin busiest wavefront: regions %d, tiles box-tested %d (maxima over the wavefronts); the slowest took %d cycles: triangles %d .." % (o[29], o[30], o[31] >> 24, (o[31] & 0xffffff) * 64))
 print("heavy tiles %d (sum survivors %d): master wave cycles per tile: setup+merge+shade %.0f, own trace %.0f, wait B2 %.0f" % (o[35], o[36], o[32]/max(o[35],1), o[33]/max(o[35],1), o[34]/max(o[35],1)))
 print("shared tiles' slices longer than a staging area: %d as far pairs (%d pairs), %d did not fit; most pairs of one slice %d" % tuple(o[43:47]))
 print("kernel ms", api.last_kernel_times(), flush=True)
