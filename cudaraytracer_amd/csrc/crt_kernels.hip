@@ -1717,9 +1717,9 @@ constexpr int kFarMaxSlice = 1024;
 #ifndef CRT_NO_FAR          // A/B switches of tuning builds
 #define CRT_NO_FAR 0
 #endif
-#ifndef CRT_NO_TL_LIGHT
-#define CRT_NO_TL_LIGHT 0
-#endif
+#ifndef CRT_TL_LIGHT        // diagnostic builds (make EXTRA=-DCRT_TL_LIGHT=1): the timeline also logs every wavefront's last light tile with
+#define CRT_TL_LIGHT 0      // geometry (tools/tiled_stats.py); off in the shipped library — its eight SGPRs of state across the light loop cost
+#endif                      // the bench frame 1-2 % through spills
 __device__ __forceinline__ unsigned build_far_pairs(unsigned short* __restrict__ out, unsigned cap, const RenderParams& p,
                                                     const float4* __restrict__ cls, int n_pad, const uint32_t* __restrict__ lst,
                                                     int first, int step, int n, int lane, bool valid, int x, int y_global,
@@ -2231,7 +2231,7 @@ shade_tiles_kernel(RenderParams p_arg, const float* __restrict__ rec, const floa
         // six waves per SIMD they were spilled to scratch (one v_mov per tile instead of a scratch reload per use)
         int lane = lane_k;
         asm volatile("" : "+v"(lane));
-        if (!CRT_NO_TL_LIGHT && timeline && tl_light_t != 0ull && tl_light_end == 0ull) tl_light_end = (unsigned long long)wall_clock64();
+        if (CRT_TL_LIGHT && timeline && tl_light_t != 0ull && tl_light_end == 0ull) tl_light_end = (unsigned long long)wall_clock64();
         const unsigned c_len = ((n_groups + (unsigned)(kLightChunks - 1 - chunk)) / kLightChunks) * kLightGroup;   // positions of this chunk
         unsigned pos = 0xffffffffu;
         if (c_len != 0u) {
@@ -2266,7 +2266,7 @@ shade_tiles_kernel(RenderParams p_arg, const float* __restrict__ rec, const floa
 #if CRT_PRIO
         if (cnt != 0) __builtin_amdgcn_s_setprio(CRT_PRIO_GEOM); else __builtin_amdgcn_s_setprio(CRT_PRIO_SKY);
 #endif
-        if (!CRT_NO_TL_LIGHT && timeline && cnt != 0) {
+        if (CRT_TL_LIGHT && timeline && cnt != 0) {
             tl_light_t = (unsigned long long)wall_clock64();
             tl_light = ((tl_light + (1ull << 48)) & 0xffff000000000000ull) | ((unsigned long long)(unsigned)cnt << 32) | (unsigned)tile_id;
             tl_counts = 0ull;
@@ -2392,7 +2392,7 @@ shade_tiles_kernel(RenderParams p_arg, const float* __restrict__ rec, const floa
 #endif
                     }
 #ifdef CRT_TL_COUNTS   // diagnostic build: wave-samples of the wave's last geometry tile with an unreachable winner
-                    if (timeline) tl_counts += __builtin_amdgcn_ballot_w64(bad) != 0ull ? 1ull : 0ull;
+                    if (CRT_TL_LIGHT && timeline) tl_counts += __builtin_amdgcn_ballot_w64(bad) != 0ull ? 1ull : 0ull;
 #endif
                     if (__builtin_amdgcn_ballot_w64(bad) == 0ull) {
                         if (hot) hit_idx = slot;
@@ -2494,10 +2494,12 @@ shade_tiles_kernel(RenderParams p_arg, const float* __restrict__ rec, const floa
             stats_in[kStatsWaveLog + 4 * gw + 2] = wall2;
             // the block's last shared tile: entries << 44 | tile << 20, and the wave's place (HW_REG_HW_ID: wave, SIMD, CU, SE)
             stats_in[kStatsWaveLog + 4 * gw + 3] = (tl_heavy << 20) | (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xfffffu);
+            if (CRT_TL_LIGHT) {
             stats_in[kStatsLightLog + 2 * gw + 0] = tl_light_t;
             stats_in[kStatsLightLog + 2 * gw + 1] = tl_light;
             // ... its duration in ticks (low 20 bits); CRT_TL_COUNTS builds: four 11-bit counts above
             stats_in[kStatsLightLog + 2 * kStatsWaveSlots + gw] = ((tl_light_end - tl_light_t) & 0xfffffull) | (tl_counts << 20);
+            }
         }
     }
 }
