@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """bin_tri_kernel on the device clock (timeline mode of crt_debug_tiled_stats): when the last wavefront ended and which
-wavefront took longest.   python tools/bin_timeline.py [C3|C5] [list|bvh]"""
+wavefront took longest.   python tools/bin_timeline.py [C3|C5] [list|bvh]
+(Three same-address atomics per wavefront: they queue up behind one another, 20 ns each — with 15 000 wavefronts the times
+printed are several times those of an undisturbed launch; what the tool is good for is WHICH wavefront is the last.)"""
 import os
 import sys
 import tempfile
