@@ -89,6 +89,11 @@ if sq_s and r.get("GRBM_GUI_ACTIVE"):
         dv["valu_pipe_busy_frac"] = r["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (dv["effective_clock_GHz"] * 1e9 * sq_s)
         if r.get("SQ_INSTS_VALU"):
             dv["valu_cycles_per_instruction"] = r["SQ_ACTIVE_INST_VALU"] * 4 / r["SQ_INSTS_VALU"]
+            # against the bound of the kernel's OWN mix: its instructions at the cycles per instruction they were measured to
+            # hold the pipe, with the pipe never idle, take frac x the pass's time — the same number as the pipe-busy fraction,
+            # named for what bench.py reports it as
+            dv["valu_mix_bound_frac"] = dv["valu_pipe_busy_frac"]
+            dv["valu_mix_bound_note"] = "SQ_INSTS_VALU x valu_cycles_per_instruction / 4 per SIMD / cycles of the pass (= pipe busy): 1.0 = the mix's own bound"
 lanes = per_pass[key].get("pmc_lanes", {})
 if lanes.get("SQ_THREAD_CYCLES_VALU") and lanes.get("SQ_ACTIVE_INST_VALU"):
     # lanes active per VALU cycle (tools/pmc_lanes.sh, round 3: 64.0 for full wavefronts, 37 for the generic kernel)
