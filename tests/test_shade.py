@@ -270,6 +270,7 @@ def test_gpu_lambert_materials_through_the_tiled_kernels_on_a_dense_pile(gpu, or
         if variant == 0:
             stats = api.tiled_stats(0)
             assert stats[4] > 0 and stats[6] > 64, stats[:8]          # the tiled kernels ran, and some tile holds more than one staging chunk
+            assert stats[43] > 0, stats[43:47]                        # ... with slices that go as far pairs (MAT instantiations)
         assert same(got, ref), (world, variant, int((bits(got) != bits(ref)).any(axis=2).sum()))
         assert np.array_equal(st.export()[1:], after[1:]), (world, variant)
 
