@@ -227,8 +227,33 @@ def main():
     # kernel) on a communicator made through the C ABI as well (crt_comm_unique_id on rank 0, broadcast over the process
     # group that torchrun set up, crt_comm_init_rank everywhere); gloo rehearsals and --gather torch use dist.gather.
     gather = "c" if (world > 1 and not share and args.gather == "c") else "torch"
-    br = BandRenderer(scene, camera, NX, NY, rank, world, seed=0, gather=gather)
+    gather_note = None
     stream = torch.cuda.current_stream()
+    br = None
+    if gather == "c":
+        # The C path is tried first — communicator, then one whole step — and every rank learns whether it worked everywhere;
+        # if not (an RCCL build the library's dlopen does not find, an IPC restriction of the node), ALL ranks go on with
+        # torch.distributed.gather and the line says so, rather than the N-GPU run dying without a number.
+        ok, why = 1, ""
+        try:
+            br = BandRenderer(scene, camera, NX, NY, rank, world, seed=0, gather="c")
+            br.render(args.spp, stream=stream)
+            br.gather()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001 — whatever went wrong, the fallback decision is collective
+            ok, why = 0, "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if br is not None:
+                try:
+                    br.close()
+                except Exception:   # noqa: BLE001
+                    pass
+            br, gather = None, "torch"
+            gather_note = "C-path exchange failed on some rank (%s): torch.distributed.gather instead" % (why or "another rank")
+    if br is None:
+        br = BandRenderer(scene, camera, NX, NY, rank, world, seed=0, gather=gather)
 
     def step():
         br.render(args.spp, stream=stream)
@@ -491,7 +516,7 @@ def main():
                                        "32-row strips dealt round-robin x%d + %s + reassembly kernel"
                                        % (world, "crt_gather_strips (C ABI: one grouped RCCL send/recv to rank 0 on a crt_comm_* communicator)"
                                           if gather == "c" else "torch.distributed.gather to rank 0")),
-                       "gather_path": gather if world > 1 else None,
+                       "gather_path": gather if world > 1 else None, "gather_note": gather_note,
                        "kernel_variant": args.variant},
             # rays x triangles: what the reference's list walk would test, NOT what the tiled kernels
             # execute (they test `tile_survivors_sum` list entries per sample and tile)
