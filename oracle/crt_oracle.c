@@ -123,8 +123,10 @@ static o_vec3 point_at_t(const o_ray *r, float t) { return add(r->_origin, muls(
  * Toolkit 12.2 (CudaTest/CudaTest.vcxproj:33), curand_kernel.h.  Restated from the
  * published algorithm: Marsaglia's xorwow recurrence + Weyl sequence, cuRAND's seed
  * scrambling constants, and the 2^67-step subsequence skip expressed as powers of the
- * GF(2) transition matrix of the xorshift part.  No known-answer vector exists offline:
- * PARITY UNPINNED at this boundary. */
+ * GF(2) transition matrix of the xorshift part.  The recurrence and both skips ARE held to an
+ * independent XORWOW — rocRAND's xorwow_engine on raw states (oracle/ref_rocrand_xorwow.cpp,
+ * tests/test_ref_xorwow.py).  The scrambling constants, the start words and curand_uniform's mapping
+ * are cuRAND's alone and no known-answer vector exists offline: PARITY UNPINNED for those. */
 
 unsigned int o_curand(o_curand_state *s) {                                /* curand_kernel.h: curand(curandStateXORWOW_t*) */
     unsigned int t;
@@ -264,6 +266,14 @@ void o_curand_init(unsigned long long seed, unsigned long long subsequence,
     state->v[3] = 88675123U ^ t1;
     state->v[4] = 5783321U + t0;
     xw_skip(state->v, subsequence, 1); /* 2^67 steps per subsequence; d unchanged (2^67*362437 == 0 mod 2^32) */
+    xw_skip(state->v, offset, 0);
+    state->d += 362437 * (unsigned int)offset;
+}
+
+/* Test hook: the two skips of _curand_init_scratch on a RAW state (no seed scrambling), so that they can be held to an
+ * independent XORWOW — rocRAND's engine, oracle/ref_rocrand_xorwow.cpp, tests/test_ref_xorwow.py. */
+void o_xorwow_skip_raw(o_curand_state *state, unsigned long long subsequence, unsigned long long offset) {
+    xw_skip(state->v, subsequence, 1);
     xw_skip(state->v, offset, 0);
     state->d += 362437 * (unsigned int)offset;
 }

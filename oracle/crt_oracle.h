@@ -17,7 +17,11 @@
  * (Two pieces of the reference ARE plain C/C++ and build from their own files, into
  * oracle/_ref/ — `make ref`: the PNG encoder WritePng calls, ref_stb_png.c, and the
  * timing table's writer, ref_csv.cpp.  They pin the product's output files byte for byte,
- * tests/test_png.py; they say nothing about the render path.)
+ * tests/test_png.py; they say nothing about the render path.  Later rounds added, the same
+ * way: core/vec3.h (ref_vec3.cpp), the hit-path headers compiled for gfx950 (ref_hit.hip),
+ * rocThrust's thrust::sort (ref_thrust_sort.hip) and rocRAND's XORWOW engine for the
+ * recurrence and the 2^67-step skips (ref_rocrand_xorwow.cpp).  DESIGN.md §2 lists what
+ * each pins and what stays unpinned.)
  *
  * Floating point: every operation is IEEE-754 binary32 evaluated in source order with
  * no contraction (build with -ffp-contract=off), except the reference's double-typed
@@ -99,6 +103,8 @@ void o_curand_init(unsigned long long seed, unsigned long long subsequence,
                    unsigned long long offset, o_curand_state *state);
 unsigned int o_curand(o_curand_state *state);
 float o_curand_uniform(o_curand_state *state);
+/* test hook: subsequence * 2^67 steps, then offset steps, on a raw state (tests/test_ref_xorwow.py) */
+void o_xorwow_skip_raw(o_curand_state *state, unsigned long long subsequence, unsigned long long offset);
 /* core/deviceManage.h:120-136: state[pi] = curand_init(seed, pi, 0) for pi in [0,nx*ny) */
 void o_set_curand_state(o_curand_state *state, int nx, int ny, unsigned long long seed);
 /* same, for an arbitrary pixel range [first, first+count) written to state[0..count) */

@@ -125,6 +125,35 @@ def curand_stream(seed, subsequence, offset, n):
     return u32, f32
 
 
+def xorwow_skip_raw(x, d, subsequence, offset):
+    """Raw states (x: n x 5 u32, d: n u32) advanced by subsequence * 2^67 + offset steps: o_xorwow_skip_raw per state."""
+    L = lib()
+    L.o_xorwow_skip_raw.argtypes = [C.POINTER(CurandState), C.c_ulonglong, C.c_ulonglong]
+    L.o_xorwow_skip_raw.restype = None
+    x = np.array(x, dtype=np.uint32).reshape(-1, 5)
+    d = np.array(d, dtype=np.uint32).reshape(-1)
+    for i in range(len(d)):
+        s = CurandState()
+        s.d = int(d[i])
+        for k in range(5):
+            s.v[k] = int(x[i, k])
+        L.o_xorwow_skip_raw(C.byref(s), int(subsequence[i]), int(offset[i]))
+        d[i] = s.d
+        x[i] = [s.v[k] for k in range(5)]
+    return x, d
+
+
+def xorwow_next_raw(x, d, count):
+    """One raw state stepped `count` times with o_curand: (outputs, x, d)."""
+    L = lib()
+    s = CurandState()
+    s.d = int(d)
+    for k in range(5):
+        s.v[k] = int(x[k])
+    out = np.array([L.o_curand(C.byref(s)) for _ in range(count)], dtype=np.uint32)
+    return out, np.array([s.v[k] for k in range(5)], dtype=np.uint32), np.uint32(s.d)
+
+
 def curand_states(first, count, seed=0):
     st = np.zeros(count, dtype=STATE_DTYPE)
     lib().o_set_curand_state_range(st.ctypes.data, first, count, seed)

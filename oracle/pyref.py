@@ -13,11 +13,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIT_PATH = os.path.join(_HERE, "_ref", "libref_hit.so")
 THRUST_PATH = os.path.join(_HERE, "_ref", "libref_thrust_sort.so")
+XORWOW_PATH = os.path.join(_HERE, "_ref", "libref_rocrand_xorwow.so")   # rocRAND's XORWOW engine on raw states (host code, no HIP runtime)
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 _hit = None
 _thrust = None
+_xorwow = None
 
 
 def _load(path):
@@ -61,6 +63,45 @@ def thrust_lib():
         L.ref_thrust_sort_device.argtypes = [C.c_int, C.c_int, _fp, _ip]
         _thrust = L
     return _thrust
+
+
+def have_xorwow():
+    return os.path.exists(XORWOW_PATH)
+
+
+def xorwow_lib():
+    global _xorwow
+    if _xorwow is None:
+        L = C.CDLL(XORWOW_PATH)
+        _up, _ullp = C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong)
+        L.ref_xorwow_skip.argtypes = [C.c_longlong, _up, _up, _ullp, _ullp]
+        L.ref_xorwow_next.argtypes = [_up, _up, C.c_longlong, _up]
+        _xorwow = L
+    return _xorwow
+
+
+def rocrand_xorwow_skip(x, d, subsequence, offset):
+    """rocRAND's xorwow_engine on raw states: x (n x 5 u32), d (n u32) advanced by subsequence * 2^67, then offset steps."""
+    x = np.array(x, dtype=np.uint32).reshape(-1, 5)
+    d = np.array(d, dtype=np.uint32).reshape(-1)
+    sub = np.ascontiguousarray(subsequence, dtype=np.uint64)
+    off = np.ascontiguousarray(offset, dtype=np.uint64)
+    assert len(sub) == len(off) == len(d) == len(x)
+    up, ullp = C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong)
+    rc = xorwow_lib().ref_xorwow_skip(len(d), x.ctypes.data_as(up), d.ctypes.data_as(up), sub.ctypes.data_as(ullp), off.ctypes.data_as(ullp))
+    assert rc == 0
+    return x, d
+
+
+def rocrand_xorwow_next(x, d, count):
+    """rocRAND's xorwow_engine::next() `count` times from one raw state: (outputs, x, d)."""
+    x = np.array(x, dtype=np.uint32).reshape(5)
+    d = np.array([d], dtype=np.uint32)
+    out = np.zeros(count, dtype=np.uint32)
+    up = C.POINTER(C.c_uint)
+    rc = xorwow_lib().ref_xorwow_next(x.ctypes.data_as(up), d.ctypes.data_as(up), count, out.ctypes.data_as(up))
+    assert rc == 0
+    return out, x, d[0]
 
 
 def _f(a):
