@@ -121,6 +121,7 @@ PROTOTYPES = {
     "crt_debug_box_hit": (C.c_int, [C.c_int, C.c_int, _fp, _fp, _fp, C.POINTER(C.c_int)]),
     "crt_debug_box_op": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "crt_debug_thrust_sort": (C.c_int, [C.c_int, _fp, C.POINTER(C.c_int)]),
+    "crt_debug_xorwow_jump": (C.c_int, [C.c_int, C.POINTER(C.c_uint)]),
     "crt_debug_force_stream_recycle": (C.c_int, [C.c_int]),
     "crt_write_png_rgba8": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]),
     "crt_encode_png_rgba8": (C.c_longlong, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_longlong]),

@@ -145,6 +145,14 @@ int crt_debug_thrust_sort(int n, const float* key, int* order) {
     return CRT_OK;
 }
 
+int crt_debug_xorwow_jump(int k, uint32_t* rows) {
+    if (k < 0 || k >= crt::kXwJumps || !rows) return fail(CRT_ERR_INVALID, "crt_debug_xorwow_jump: bad argument");
+    const std::vector<uint32_t>& jt = jump_table();
+    const size_t words = (size_t)crt::kXwBits * crt::kXwWords;
+    std::copy(jt.begin() + (size_t)k * words, jt.begin() + (size_t)(k + 1) * words, rows);
+    return CRT_OK;
+}
+
 int crt_debug_force_stream_recycle(int count) {
     const int prev = g_force_stream_recycle;
     g_force_stream_recycle = count < 0 ? 0 : count;

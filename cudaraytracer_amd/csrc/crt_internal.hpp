@@ -74,6 +74,7 @@ int ensure_records(Context& cx, int n_tris, int n_pad);
 int ensure_workspace(Context& ws, int nx, int rows, int n_tris);
 bool have_device();
 void rotation_zero_matrix(float m[9]);
+const std::vector<uint32_t>& jump_table();   // crt_api.cpp: the 64 XORWOW jump matrices rng_init_kernel walks
 void debug_thrust_sort(int* order, int n, const float* key);                     // crt_bvh.cpp: the build's sort
 void debug_host_box_op(int op, const float* a6, const float* b6, float* out6);   // crt_bvh.cpp: the build's box helpers
 extern int g_force_stream_recycle;                                               // crt_api.cpp: crt_debug_force_stream_recycle

@@ -149,6 +149,11 @@ int crt_debug_box_op(int where, int op, int n, const float *a6, const float *b6,
  * rocThrust's real thrust::sort by tests/test_ref_thrust.py. */
 int crt_debug_thrust_sort(int n, const float *key, int *order);
 
+/* Matrix k (0..63) of the table rng_init_kernel walks: T^(2^(67+k)), T = the GF(2) transition matrix of XORWOW's xorshift
+ * part; rows[160][5], row b = image of state bit b (word b/32, bit b%32).  Host only; held to rocRAND's precomputed jump
+ * matrices by tests/test_ref_xorwow.py. */
+int crt_debug_xorwow_jump(int k, uint32_t *rows);
+
 /* Test hook for the recycled-stream branch of the launch contexts: the next `count` context look-ups treat their stream
  * as a NEW stream behind an old handle (what a changed hipStreamGetId means on HIP >= 7.1 runtimes; PyTorch's bundled
  * 7.0 runtime has no hipStreamGetId, so without this hook the branch never runs there).  Returns the previous count. */

@@ -100,3 +100,36 @@ def test_curand_init_is_scramble_then_pinned_skip():
             x, d = po.xorwow_skip_raw(x0[None, :], [d0], [pixel], [0])
             st = po.curand_states(pixel, 1, seed)
             assert int(st["d"][0]) == int(d[0]) and st["v"][0].tolist() == x[0].tolist(), (seed, pixel)
+
+
+def test_product_jump_matrices_equal_rocrand(g):
+    """The table the product's rng_init_kernel walks (csrc/crt_api.cpp: jump_table, matrix k = T^(2^(67+k))), row by row:
+    matrix 0 = one subsequence, matrix 32 = 2^32 subsequences, against rocRAND's precomputed matrices applied to single-bit
+    states; and every matrix applied to the fixture's random states against rocRAND's discard_subsequence(2^k).  Host
+    only (the device walk of the same table is held to the oracle by tests/test_gpu_parity.py)."""
+    import ctypes as C
+    from cudaraytracer_amd import _lib
+    crt = _lib.lib()
+    rows = np.zeros((160, 5), dtype=np.uint32)
+
+    def matrix(k):
+        assert crt.crt_debug_xorwow_jump(k, rows.ctypes.data_as(C.POINTER(C.c_uint))) == 0
+        return rows.copy()
+
+    assert crt.crt_debug_xorwow_jump(64, rows.ctypes.data_as(C.POINTER(C.c_uint))) != 0
+    assert np.array_equal(matrix(0), g["bits_seq1"])
+    assert np.array_equal(matrix(32), g["bits_seq_hi"])
+    # subsequence counts with a single binary digit: d << 2p with d = 1 (k = 2p) and d = 2 (k = 2p + 1)
+    sub = g["subsequence"]
+    seen = set()
+    for i in np.nonzero((g["offset"] == 0) & (sub > 0) & ((sub & (sub - np.uint64(1))) == 0))[0]:
+        k = int(sub[i]).bit_length() - 1
+        m = matrix(k)
+        v = np.zeros(5, dtype=np.uint32)
+        for w in range(5):
+            for b in range(32):
+                if (int(g["x"][i, w]) >> b) & 1:
+                    v ^= m[w * 32 + b]
+        assert np.array_equal(v, g["x_out"][i]), k
+        seen.add(k)
+    assert seen == set(range(64))
