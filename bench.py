@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)   # profiling: only launches of the timed frame
     ap.add_argument("--gather", choices=("c", "torch"), default="c", help=argparse.SUPPRESS)   # N > 1: the C ABI's exchange (crt_gather_strips over an ncclComm_t
                                                                                              # made with crt_comm_*) or torch.distributed.gather (fallback)
+    ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)             # N > 1, C path: the exchange on the render's own stream
+                                                                                             # (default: on a stream of its own, frame k's exchange under frame k + 1's kernels)
     ap.add_argument("--clock-warm-s", type=float, default=0.3, help=argparse.SUPPRESS)        # untimed frames before the timed passes (clock ramp)
     args = ap.parse_args()
 
@@ -236,7 +238,7 @@ def main():
         # torch.distributed.gather and the line says so, rather than the N-GPU run dying without a number.
         ok, why = 1, ""
         try:
-            br = BandRenderer(scene, camera, NX, NY, rank, world, seed=0, gather="c")
+            br = BandRenderer(scene, camera, NX, NY, rank, world, seed=0, gather="c", overlap=not args.no_overlap)
             br.render(args.spp, stream=stream)
             br.gather()
             torch.cuda.synchronize()
@@ -261,7 +263,8 @@ def main():
         return full
 
     def fence():
-        if world > 1:
+        br.wait(stream)                                    # overlapped exchange: the launch stream behind the last one, so the barrier's
+        if world > 1:                                      # collective is enqueued after every exchange of this rank, as without overlap
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -514,8 +517,11 @@ def main():
                        "nx": NX, "ny": NY, "spp": args.spp, "triangles": n_tris,
                        "parallelism": ("1 GPU, one launch" if world == 1 else
                                        "32-row strips dealt round-robin x%d + %s + reassembly kernel"
-                                       % (world, "crt_gather_strips (C ABI: one grouped RCCL send/recv to rank 0 on a crt_comm_* communicator)"
+                                       % (world, "crt_gather_strips (C ABI: one grouped RCCL send/recv to rank 0 on a crt_comm_* communicator%s)"
+                                          % (", on a stream of its own: frame k's exchange runs under frame k+1's kernels, two pieces in turn"
+                                             if br.overlap else "")
                                           if gather == "c" else "torch.distributed.gather to rank 0")),
+                       "exchange_overlapped": bool(br.overlap) if world > 1 else None,
                        "gather_path": gather if world > 1 else None, "gather_note": gather_note,
                        "kernel_variant": args.variant},
             # rays x triangles: what the reference's list walk would test, NOT what the tiled kernels

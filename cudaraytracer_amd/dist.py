@@ -126,9 +126,19 @@ class BandRenderer:
     + its device buffer.  mode "strips" (default when world_size > 1) or "bands"."""
 
     def __init__(self, scene, camera, nx, ny, rank, world_size, seed=0, device="cuda", mode=None, bvh=False, gather="torch",
-                 group=None):
+                 group=None, overlap=False):
         from . import api
         self.api = api
+        # overlap (C path only): the exchange of frame k runs on a stream of its own while frame k + 1 renders — two pieces
+        # in turn, an event each way: the exchange waits for its frame's kernels, the render of frame k + 2 waits until the
+        # exchange of frame k has read the piece it is about to overwrite.  gather() then returns rank 0's frame buffer as it
+        # will be once the exchange stream has run (wait() orders a caller's stream behind it; a device synchronise does too).
+        self.overlap = bool(overlap) and gather == "c"
+        self._xstream = None
+        self._slot = 0
+        self._rendered = [None, None]
+        self._gathered = [None, None]
+        self._bands = None
         self.bvh = bool(bvh)                 # world = the scene's BVHNode tree (crt_scene_build_bvh) instead of its list
         # gather "c": the exchange step behind the C ABI — crt_gather_strips (one grouped ncclSend / ncclRecv to rank 0 + the
         # reassembly kernel, csrc/crt_multi.cpp) on a communicator made with crt_comm_unique_id / crt_comm_init_rank; the 128
@@ -159,7 +169,10 @@ class BandRenderer:
             if self.mode != "strips":
                 raise ValueError("gather='c' needs the strip partition (crt_gather_strips)")
             self.bufs = None
-            self.band = like.new_zeros(max(self.row_count, 1) * nx * 3)[: self.row_count * nx * 3]
+            self._bands = [like.new_zeros(max(self.row_count, 1) * nx * 3)[: self.row_count * nx * 3] for _ in range(2 if self.overlap else 1)]
+            self.band = self._bands[0]
+            if self.overlap:
+                self._xstream = torch.cuda.Stream(device=like.device)
             self.part_stride = api.strip_part_stride(nx, ny, STRIP_ROWS, world_size)
             if rank == 0:
                 self._parts = like.new_empty(self.part_stride * world_size)
@@ -182,6 +195,8 @@ class BandRenderer:
         return api.comm_init_rank(self.world_size, bytes(ident.cpu().numpy().tobytes()), self.rank)
 
     def close(self):
+        if self._xstream is not None:
+            self._xstream.synchronize()
         if self.comm:
             self.api.comm_destroy(self.comm)
             self.comm = None
@@ -189,7 +204,12 @@ class BandRenderer:
     def render(self, samples, frame_index=0, stream=None):
         """Enqueue this rank's rows (no synchronisation)."""
         stream = stream if stream is not None else torch.cuda.current_stream()
+        if self.overlap:
+            self.band = self._bands[self._slot]
+            if self._gathered[self._slot] is not None:
+                stream.wait_event(self._gathered[self._slot])     # the exchange two frames back has read this piece
         if self.row_count == 0:
+            self._mark_rendered(stream)
             return
         if self.mode == "strips":
             self.api.render_strips(self.scene, self.camera, self.state, self.nx, self.ny, samples, self.rank,
@@ -198,8 +218,32 @@ class BandRenderer:
             self.api.render_rows(self.scene, self.camera, self.state, self.nx, self.ny, samples,
                                  self.row_begin, self.row_count, self.band, frame_index=frame_index,
                                  stream=stream, bvh=self.bvh)
+        self._mark_rendered(stream)
+
+    def _mark_rendered(self, stream):
+        if self.overlap:
+            ev = self._rendered[self._slot] or torch.cuda.Event()
+            ev.record(stream)
+            self._rendered[self._slot] = ev
+
+    def wait(self, stream=None):
+        """Order `stream` (default: the current one) behind the last exchange (overlap mode; otherwise nothing to do)."""
+        last = self._gathered[self._slot ^ 1] if self.overlap else None
+        if last is not None:
+            (stream if stream is not None else torch.cuda.current_stream()).wait_event(last)
 
     def gather(self, group=None, stream=None):
+        if self.gather_path == "c" and self.overlap:
+            xs, slot = self._xstream, self._slot
+            if self._rendered[slot] is not None:
+                xs.wait_event(self._rendered[slot])
+            self.api.gather_strips(self._bands[slot] if self.row_count else None, self.nx, self.ny, STRIP_ROWS, self.rank, self.world_size,
+                                   self._parts, self.part_stride, self._full, self.comm, stream=xs)
+            ev = self._gathered[slot] or torch.cuda.Event()
+            ev.record(xs)
+            self._gathered[slot] = ev
+            self._slot ^= 1
+            return self._full.view(self.ny, self.nx, 3) if self.rank == 0 else None
         if self.gather_path == "c":
             stream = stream if stream is not None else torch.cuda.current_stream()
             self.api.gather_strips(self.band if self.row_count else None, self.nx, self.ny, STRIP_ROWS, self.rank, self.world_size,

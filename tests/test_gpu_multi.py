@@ -408,11 +408,14 @@ def test_one_call_render_is_repeatable_and_keeps_its_buffers(gpu, crt_built, ora
     assert np.array_equal(bits(api.render(nx, ny, spp, scene, cam, seed=0)), bits(a))
 
 
-def test_band_renderer_c_path_gather_world_one(gpu):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_band_renderer_c_path_gather_world_one(gpu, overlap):
     """What bench.py --gpus N runs per rank over RCCL, at world 1: the communicator comes from the C ABI
     (crt_comm_unique_id + crt_comm_init_rank = ncclGetUniqueId + ncclCommInitRank), the exchange step is crt_gather_strips
-    (the root's send to itself goes through RCCL), the frame equals the single-launch frame; two frames continue the
-    streams."""
+    (the root's send to itself goes through RCCL), the frame equals the single-launch frame; the frames continue the
+    streams.  overlap: the exchange of frame k on a stream of its own while frame k + 1 renders into the other piece —
+    five frames enqueued back to back without a host synchronisation in between, each copied out on the caller's stream
+    behind wait()."""
     from cudaraytracer_amd.dist import BandRenderer
     sc = scenes.displaced_sphere(24, 30)
     nx, ny, spp = 200, 150, 3
@@ -420,18 +423,30 @@ def test_band_renderer_c_path_gather_world_one(gpu):
     st = api.SetCurandState(nx, ny, 0)
     d = gpu.zeros(ny * nx * 3, dtype=gpu.float32, device="cuda")
     wants = []
-    for _ in range(2):
+    n_frames = 5 if overlap else 2
+    for _ in range(n_frames):
         api.render_rows(scene, cam, st, nx, ny, spp, 0, ny, d, stream=gpu.cuda.current_stream())
         gpu.cuda.synchronize()
         wants.append(d.cpu().numpy().reshape(ny, nx, 3).copy())
-    br = BandRenderer(scene, cam, nx, ny, 0, 1, seed=0, mode="strips", gather="c")
+    br = BandRenderer(scene, cam, nx, ny, 0, 1, seed=0, mode="strips", gather="c", overlap=overlap)
     try:
-        assert br.gather_path == "c" and br.comm
-        for k in range(2):
-            br.render(spp)
-            full = br.gather()
+        assert br.gather_path == "c" and br.comm and br.overlap == overlap
+        if overlap:
+            copies = []
+            for k in range(n_frames):
+                br.render(spp)
+                full = br.gather()
+                br.wait()                       # the caller's stream behind the exchange of frame k
+                copies.append(full.clone())     # ... and the next exchange behind this copy (it follows the next render's event)
             gpu.cuda.synchronize()
-            assert np.array_equal(bits(full.cpu().numpy()), bits(wants[k])), k
+            for k in range(n_frames):
+                assert np.array_equal(bits(copies[k].cpu().numpy()), bits(wants[k])), k
+        else:
+            for k in range(n_frames):
+                br.render(spp)
+                full = br.gather()
+                gpu.cuda.synchronize()
+                assert np.array_equal(bits(full.cpu().numpy()), bits(wants[k])), k
     finally:
         br.close()
     assert br.comm is None
