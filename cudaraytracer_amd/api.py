@@ -485,12 +485,26 @@ def set_kernel_variant(v):
     return _lib.lib().crt_set_kernel_variant(int(v))
 
 
-def render(nx, ny, samples, scene, camera, seed=0, max_depth=8, frame_index=0):
-    """One frame through crt_render: float32 array [ny, nx, 3], row 0 = image bottom."""
-    out = np.zeros((ny, nx, 3), dtype=np.float32)
+def render(nx, ny, samples, scene, camera, seed=0, max_depth=8, frame_index=0, out=None):
+    """One frame through crt_render: float32 array [ny, nx, 3], row 0 = image bottom.
+    out: the caller's host buffer of ny*nx*3 floats to render into — a numpy array or a CPU torch tensor; a PAGE-LOCKED one
+    (torch.empty(..., pin_memory=True), hipHostMalloc) takes the frame at the link's rate, a pageable one through the
+    runtime's staging."""
+    if out is None:
+        out = np.zeros((ny, nx, 3), dtype=np.float32)
+        ptr, ret = _fp(out), out
+    elif isinstance(out, np.ndarray):
+        if out.dtype != np.float32 or out.size != ny * nx * 3 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("render: out must be a C-contiguous float32 array of ny*nx*3 elements")
+        ptr, ret = _fp(out), out.reshape(ny, nx, 3)
+    else:   # a CPU torch tensor
+        import torch
+        if out.device.type != "cpu" or out.dtype != torch.float32 or out.numel() != ny * nx * 3 or not out.is_contiguous():
+            raise ValueError("render: out must be a contiguous float32 CPU tensor of ny*nx*3 elements")
+        ptr, ret = C.cast(C.c_void_p(out.data_ptr()), C.POINTER(C.c_float)), out.numpy().reshape(ny, nx, 3)
     check(_lib.lib().crt_render(nx, ny, samples, max_depth, frame_index, scene.handle,
-                                C.byref(camera.c), int(seed), _fp(out)))
-    return out
+                                C.byref(camera.c), int(seed), ptr))
+    return ret
 
 
 def to_rgba8(rgb):
@@ -511,6 +525,23 @@ def WritePng(nx, ny, frameIndex, colorBuffer, folder="images/moveTest"):
     return path
 
 
+def _pinned_frame(nx, ny):
+    """The frame loops' host buffer (the reference's `colorBuffer`, a malloc): page-locked, so the copy back runs at the
+    link's rate behind the render kernel on its stream instead of through the runtime's staging of a pageable copy."""
+    import torch
+    return torch.empty(ny * nx * 3, dtype=torch.float32, pin_memory=True)
+
+
+def _copy_back(h_colorBuffer, d_colorBuffer, nx, ny):
+    """cudaDeviceSynchronize + cudaMemcpy(colorBuffer, d_colorBuffer) of the frame loops (render.h:180-183,222-225): the copy
+    enqueued behind the frame's kernels, ONE synchronisation; returns the host buffer as a [ny, nx, 3] array (the next frame
+    overwrites it, as the reference's does: keep a copy to keep the frame)."""
+    import torch
+    h_colorBuffer.copy_(d_colorBuffer, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return h_colorBuffer.numpy().reshape(ny, nx, 3)
+
+
 def renderListAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world, camera,
                         curand_state, write_png=True, folder="images/moveTest", poses=None):
     """renderListAnimation, core/render.h:159-189: per frame [update the mesh pose,] launch the
@@ -522,6 +553,7 @@ def renderListAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world,
     if not torch.cuda.is_available():
         raise CrtError(_lib.CRT_ERR_NO_DEVICE, "renderListAnimation: no HIP device (no CPU fallback)")
     d_colorBuffer = torch.zeros(ny * nx * 3, dtype=torch.float32, device="cuda")
+    h_colorBuffer = _pinned_frame(nx, ny)
     frames = []
     for frameIndex in range(beginFrame, endFrame + 1):
         if poses is not None:                                   # updateFBXObj(frameIndex, obj, ...), render.h:177
@@ -529,11 +561,10 @@ def renderListAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world,
         render_rows(world, camera, curand_state, nx, ny, samples, 0, ny, d_colorBuffer,
                     max_depth=max_depth, frame_index=frameIndex,
                     stream=torch.cuda.current_stream())
-        torch.cuda.synchronize()
-        colorBuffer = d_colorBuffer.cpu().numpy().reshape(ny, nx, 3)
+        colorBuffer = _copy_back(h_colorBuffer, d_colorBuffer, nx, ny)
         if write_png:
             WritePng(nx, ny, frameIndex, colorBuffer, folder)
-        frames.append(colorBuffer)
+        frames.append(colorBuffer.copy())
     return frames
 
 
@@ -570,6 +601,7 @@ def renderBVHAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world, 
     if not torch.cuda.is_available():
         raise CrtError(_lib.CRT_ERR_NO_DEVICE, "renderBVHAnimation: no HIP device (no CPU fallback)")
     d_colorBuffer = torch.zeros(ny * nx * 3, dtype=torch.float32, device="cuda")
+    h_colorBuffer = _pinned_frame(nx, ny)
     stream = torch.cuda.current_stream()
     frames = []
     for frameIndex in range(beginFrame, endFrame + 1):
@@ -582,13 +614,12 @@ def renderBVHAnimation(nx, ny, samples, max_depth, beginFrame, endFrame, world, 
         t0 = time.perf_counter()
         render_rows(world, camera, curand_state, nx, ny, samples, 0, ny, d_colorBuffer, max_depth=max_depth,
                     frame_index=frameIndex, stream=stream, bvh=True)
-        torch.cuda.synchronize()
-        colorBuffer = d_colorBuffer.cpu().numpy().reshape(ny, nx, 3)
+        colorBuffer = _copy_back(h_colorBuffer, d_colorBuffer, nx, ny)
         render_time = time.perf_counter() - t0
         data.append([str(frameIndex), "%f" % render_time, "%f" % update_time, ""])
         if write_png:
             WritePng(nx, ny, frameIndex, colorBuffer, folder)
-        frames.append(colorBuffer)
+        frames.append(colorBuffer.copy())
     return frames
 
 

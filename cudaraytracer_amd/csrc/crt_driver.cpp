@@ -96,6 +96,10 @@ int main(int argc, char** argv) {
         }
         float* d_colorBuffer = nullptr;
         if (hipMalloc(&d_colorBuffer, colorBuffer.size() * sizeof(float)) != hipSuccess) { fprintf(stderr, "crt_driver: hipMalloc failed\n"); return 1; }
+        // the frame's host buffer (the reference's malloc'ed colorBuffer, render.h:165): page-locked, so the copy back runs at the
+        // link's rate right behind the frame's kernels and the frame costs ONE synchronisation
+        float* h_colorBuffer = nullptr;
+        if (hipHostMalloc(&h_colorBuffer, colorBuffer.size() * sizeof(float), hipHostMallocDefault) != hipSuccess) { fprintf(stderr, "crt_driver: hipHostMalloc failed\n"); return 1; }
         for (int frame = beginFrame; frame < beginFrame + n_frames; ++frame) {                // core/render.h:174 / :207
             auto t0 = std::chrono::steady_clock::now();
             if (world_kind == CRT_WORLD_BVH) {
@@ -106,16 +110,17 @@ int main(int argc, char** argv) {
             t0 = std::chrono::steady_clock::now();
             if (crt_render_rows_ex(world, &camera, curand_state, nx, ny, samples, max_depth, frame, 0, ny, world_kind, shader,
                                    d_colorBuffer, nullptr) != CRT_OK) return die("crt_render_rows_ex");
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpy(colorBuffer.data(), d_colorBuffer, colorBuffer.size() * sizeof(float), hipMemcpyDeviceToHost);
+            if (hipMemcpyAsync(h_colorBuffer, d_colorBuffer, colorBuffer.size() * sizeof(float), hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+                hipStreamSynchronize(nullptr) != hipSuccess) { fprintf(stderr, "crt_driver: copying the frame back failed\n"); return 1; }   // render.h:180-183
             rendering.push_back(seconds_since(t0));
             frames.push_back(frame);
             const std::string path = out + "/picture_" + std::to_string(frame) + ".png";
-            if (crt_write_png(path.c_str(), nx, ny, colorBuffer.data()) != CRT_OK) return die("crt_write_png");
+            if (crt_write_png(path.c_str(), nx, ny, h_colorBuffer) != CRT_OK) return die("crt_write_png");
             printf("frame %d: %d triangles, %dx%dx%d, render %.3f ms, update %.3f ms -> %s\n", frame, crt_scene_triangle_count(world), nx, ny,
                    samples, rendering.back() * 1e3, update.back() * 1e3, path.c_str());
         }
         (void)hipFree(d_colorBuffer);
+        (void)hipHostFree(h_colorBuffer);
         crt_rng_free(curand_state);
         crt_scene_free(world);
     }

@@ -191,7 +191,9 @@ int crt_render_strips(const crt_scene *scene, const crt_camera *camera, crt_rng 
  * restore instead of a re-initialisation) and the device colour buffer are kept per device between calls and freed
  * by crt_stream_release(NULL).  Calls are serialised per process.  A frame LOOP should use crt_rng_create +
  * crt_render_rows on its own stream and buffers: the states then advance from frame to frame as the reference's
- * do (core/render.h:174-186) and nothing crosses PCIe unless the host asks. */
+ * do (core/render.h:174-186) and nothing crosses PCIe unless the host asks.  rgb_out may be any host memory; a
+ * page-locked buffer (hipHostMalloc / hipHostRegister) takes the frame at the link's rate, a pageable one goes through
+ * the runtime's staging copy (bench.py: pcie_inclusive_one_call reports both). */
 int crt_render(int nx, int ny, int samples, int max_depth, int frame_index,
                const crt_scene *scene, const crt_camera *camera, uint64_t seed,
                float *rgb_out);

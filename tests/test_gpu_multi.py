@@ -406,6 +406,16 @@ def test_one_call_render_is_repeatable_and_keeps_its_buffers(gpu, crt_built, ora
     assert np.array_equal(bits(e), bits(ref2))
     assert crt_built.crt_stream_release(None) == 0
     assert np.array_equal(bits(api.render(nx, ny, spp, scene, cam, seed=0)), bits(a))
+    # into the caller's buffers: a page-locked tensor, a numpy array; wrong shapes are refused before the call
+    pinned = gpu.empty(ny * nx * 3, dtype=gpu.float32, pin_memory=True)
+    got = api.render(nx, ny, spp, scene, cam, seed=0, out=pinned)
+    assert np.array_equal(bits(got), bits(a)) and got.ctypes.data == pinned.data_ptr()
+    mine = np.full((ny, nx, 3), np.nan, dtype=np.float32)
+    assert np.array_equal(bits(api.render(nx, ny, spp, scene, cam, seed=0, out=mine)), bits(a)) and np.array_equal(bits(mine), bits(a))
+    with pytest.raises(ValueError):
+        api.render(nx, ny, spp, scene, cam, seed=0, out=np.zeros(5, dtype=np.float32))
+    with pytest.raises(ValueError):
+        api.render(nx, ny, spp, scene, cam, seed=0, out=gpu.empty(ny * nx * 3, dtype=gpu.float64))
 
 
 @pytest.mark.parametrize("overlap", [False, True])
