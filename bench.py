@@ -423,6 +423,7 @@ def main():
             "rendering_ms_mean": float(ren.mean() * 1e3), "rendering_ms_median": float(np.median(ren) * 1e3),
             "rendering_ms_first": float(ren[0] * 1e3),
             "update_ms_mean": float(upd.mean() * 1e3), "update_ms_median": float(np.median(upd) * 1e3),
+            "update_ms_first": float(upd[0] * 1e3), "update_ms_max": float(upd.max() * 1e3),
             "Mrays/s_per_frame_median": rnx * rny * rspp / float(np.median(ren)) / 1e6,
             "csv_bytes": os.path.getsize(csv_path),
             "note": "host wall clock per frame as the reference's StopWatch brackets it: 'rendering' includes the synchronise and the "
