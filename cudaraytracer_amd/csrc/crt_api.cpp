@@ -1195,7 +1195,7 @@ int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t* mismatches) {
 int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t* mismatches) {
     // Exhaustive self-check of the 3-instruction reciprocal used by the kernels on bounded
     // scenes: all floats with biased exponent in [exp_lo, exp_hi], both signs.
-    if (!mismatches || exp_lo < 0 || exp_hi > 255 || exp_lo > exp_hi || mode < 0 || mode > 3)
+    if (!mismatches || exp_lo < 0 || exp_hi > 255 || exp_lo > exp_hi || mode < 0 || mode > 4)
         return fail(CRT_ERR_INVALID, "crt_debug_check_reciprocal: bad range");
     if (!have_device()) return fail(CRT_ERR_NO_DEVICE, "crt_debug_check_reciprocal: no HIP device");
     unsigned long long* d = nullptr;

@@ -53,7 +53,9 @@ __device__ __forceinline__ uint32_t xw_next(Xorwow& s) {
 __device__ __forceinline__ float xw_uniform(Xorwow& s) {
     uint32_t x = xw_next(s);
     const float k = 2.3283064e-10f;
-    return (float)x * k + (k / 2.0f);
+    // (float)x * 2^-32 is exact (a power-of-two scaling of 0 or a float >= 1: no rounding, no underflow), so the fused form rounds
+    // once where the reference's product-then-sum rounds once: the same bits for every x, one instruction less per draw
+    return __builtin_fmaf((float)x, k, k / 2.0f);
 }
 
 // 2.0f * curand_uniform(state) - 1.0f (material.h:14, camera.h:9): doubling is exact and commutes with the rounding of
@@ -62,7 +64,7 @@ __device__ __forceinline__ float xw_uniform(Xorwow& s) {
 __device__ __forceinline__ float xw_uniform_2m1(Xorwow& s) {
     uint32_t x = xw_next(s);
     const float k = 4.6566129e-10f;   // 2^-31
-    return ((float)x * k + (k / 2.0f)) - 1.0f;
+    return __builtin_fmaf((float)x, k, k / 2.0f) - 1.0f;   // (the product is exact: see xw_uniform)
 }
 
 // random_init (core/deviceManage.h:120-128): curand_init(seed, pixel_index, 0).
@@ -2942,10 +2944,27 @@ check_reciprocal_kernel(uint32_t exp_lo, uint32_t exp_hi, unsigned long long* __
 // mode 2: every float divisor of the biased-exponent range [lo, hi], 64 pseudo-random numerators
 //         each with exponents 0..60 below the divisor's and random signs (scaling / sign paths).
 // mode 3: sqrt_normal against sqrtf for every positive float of the biased-exponent range.
+// mode 4: the fused forms of xw_uniform / xw_uniform_2m1 against curand_uniform's literal product-then-sum
+//         (x * 2^-32 + 2^-33, and 2.0f * that - 1.0f), for ALL 2^32 values of a draw.
 __global__ void __launch_bounds__(256)
 check_division_kernel(int mode, uint32_t lo, uint32_t hi, unsigned long long* __restrict__ bad) {
     unsigned long long mine = 0;
-    if (mode == 3) {   // sqrt_normal == sqrtf for every float with biased exponent in [lo, hi]
+    if (mode == 4) {
+        unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i < (1ull << 32); i += (unsigned long long)gridDim.x * blockDim.x) {
+            const uint32_t x = (uint32_t)i;
+            const float k = 2.3283064e-10f;                                 // CURAND_2POW32_INV
+            float prod = (float)x * k;
+            asm volatile("" : "+v"(prod));                                  // the product as a value of its own: no contraction, whatever the flags
+            const float u = prod + (k / 2.0f);                              // _curand_uniform
+            const float m = 2.0f * u - 1.0f;                                // material.h:14, camera.h:9
+            const float uf = __builtin_fmaf((float)x, k, k / 2.0f);         // xw_uniform
+            const float k2 = 4.6566129e-10f;
+            const float mf = __builtin_fmaf((float)x, k2, k2 / 2.0f) - 1.0f;   // xw_uniform_2m1
+            mine += (__float_as_uint(u) != __float_as_uint(uf)) ? 1ull : 0ull;
+            mine += (__float_as_uint(m) != __float_as_uint(mf)) ? 1ull : 0ull;
+        }
+    } else if (mode == 3) {   // sqrt_normal == sqrtf for every float with biased exponent in [lo, hi]
         unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
         const unsigned long long total = (unsigned long long)(hi - lo + 1) << 23;
         for (; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {

@@ -83,7 +83,9 @@ int crt_debug_check_reciprocal(int exp_lo, int exp_hi, uint64_t *mismatches);
  * mode 2 = every float divisor with biased exponent in [exp_lo, exp_hi], 64 pseudo-random
  * numerators each, exponents up to 60 below the divisor's, both signs; mode 3 = the kernel's
  * square root of normal floats (v_sqrt_f32 + neighbour residuals) against sqrtf for every positive
- * float with biased exponent in [exp_lo, exp_hi]. */
+ * float with biased exponent in [exp_lo, exp_hi]; mode 4 = the kernels' fused forms of curand_uniform and of
+ * 2.0f * curand_uniform - 1.0f (the product x * 2^-32 is exact, so one fma rounds as the literal product-then-sum does) against
+ * the literal forms for ALL 2^32 values of a draw (exp_lo, exp_hi ignored: pass 0, 0). */
 int crt_debug_check_division(int mode, int exp_lo, int exp_hi, uint64_t *mismatches);
 
 /* One core/vec3.h operation at a time on arrays (a, b, out: n x 3 floats, s: n floats; host pointers): where = 0 the

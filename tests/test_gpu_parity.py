@@ -84,6 +84,14 @@ def test_fast_sqrt_is_exact(gpu, crt_built):
     assert bad.value == 0
 
 
+def test_fused_uniform_forms_are_exact(gpu, crt_built):
+    """curand_uniform = x * 2^-32 + 2^-33 (two operations; the product is a power-of-two scaling of a float, hence exact) and
+    2.0f * u - 1.0f are computed with ONE fma for the sum in the kernels: the same bits for EVERY one of the 2^32 draws."""
+    bad = C.c_uint64(123)
+    assert crt_built.crt_debug_check_division(4, 0, 0, C.byref(bad)) == 0
+    assert bad.value == 0
+
+
 def test_unbounded_scene_uses_ieee_division_and_brute_force(gpu, oracle, crt_built):
     """Coordinates beyond 2^38: no tiling, no fast reciprocal — still the reference's pixels."""
     sc = scenes.random_soup(40, 5)
