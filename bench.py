@@ -480,7 +480,7 @@ def main():
         # committed rocprofv3 PMC passes of this very command (tools/profile_bench.sh; the summary
         # names the commit it was taken at).  The kernel time they are divided by IS this run's.
         traffic, traffic_src, valu = None, None, None
-        for prof in ("r4b_tiled", "r4_tiled", "r3_tiled", "r2_tiled", "r1_tiled"):
+        for prof in ("r4c_tiled", "r4b_tiled", "r4_tiled", "r3_tiled", "r2_tiled", "r1_tiled"):
             pmc = os.path.join(ROOT, "profiles", prof, "pmc_summary_%s.json" % ("shade" if dom.startswith("shade") else "bin_walk"))
             if os.path.exists(pmc):
                 break
